@@ -1,0 +1,146 @@
+/*
+ * iris_hifigan.h -- C-ABI of the MI355X (gfx950) HiFiGAN generator path.
+ *
+ * The reference (ZECTBynmo/iris-tts) is pure Python and has no FFI for this path
+ * (SURVEY.md section 8b): its boundary is two Python call surfaces,
+ *   iris.hifigan_pretrained.HiFiGANGenerator.__call__   (src/iris/hifigan_pretrained.py:208-242)
+ *   iris.vocoder.HiFiGANVocoder.infer                   (src/iris/vocoder.py:177-209)
+ * both of which end in one call of the generator forward
+ *   HiFiGANModel.forward                                (src/iris/hifigan_pretrained.py:123-143)
+ *   HiFiGANGenerator.call                               (src/iris/vocoder.py:103-130).
+ * The entry points below are what a binding for that forward has to provide; the
+ * drop-in Python modules in iris-tts_amd/iris/ bind them with ctypes.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer named *_dev is a HIP device pointer
+ *     owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr()), *_host is host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); forward is
+ *     asynchronous on it and performs no allocation and no synchronisation;
+ *   - every function returns an iris_hifigan_status; on failure the calling thread's
+ *     message is available from iris_hifigan_last_error(); no exception crosses the ABI;
+ *   - a handle may be used by one thread at a time.
+ *
+ * Activations inside the library are channels-last [B, L, C] fp32; the mel comes in as the
+ * reference hands it over, channels-first [B, n_mels, T] (hifigan_pretrained.py:228), and the
+ * waveform goes out as [B, prod(upsample_rates) * T] (hifigan_pretrained.py:235-236).
+ */
+#ifndef IRIS_HIFIGAN_H
+#define IRIS_HIFIGAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRIS_HIFIGAN_ABI_VERSION 1
+#define IRIS_HIFIGAN_MAX_STAGES 8    /* upsample stages            */
+#define IRIS_HIFIGAN_MAX_KERNELS 8   /* MRF branches per stage     */
+#define IRIS_HIFIGAN_MAX_DILATIONS 8 /* conv pairs per ResBlock    */
+
+typedef enum iris_hifigan_status {
+    IRIS_HIFIGAN_OK = 0,
+    IRIS_HIFIGAN_INVALID_ARGUMENT = 1,
+    IRIS_HIFIGAN_HIP_ERROR = 2,
+    IRIS_HIFIGAN_OUT_OF_MEMORY = 3,
+    IRIS_HIFIGAN_UNSUPPORTED = 4,
+    IRIS_HIFIGAN_WORKSPACE_TOO_SMALL = 5
+} iris_hifigan_status;
+
+typedef enum iris_hifigan_dtype {
+    IRIS_HIFIGAN_F32 = 0 /* fp32 storage, fp32 MFMA (exact fmaf chains) */
+} iris_hifigan_dtype;
+
+/* Generator hyper-parameters: the constructor arguments of HiFiGANModel
+ * (hifigan_pretrained.py:77-85) == HiFiGANGenerator (vocoder.py:59-67). */
+typedef struct iris_hifigan_config {
+    int32_t in_channels;              /* 80  */
+    int32_t upsample_initial_channel; /* 512 */
+    int32_t num_upsamples;            /* 4   */
+    int32_t upsample_rates[IRIS_HIFIGAN_MAX_STAGES];        /* 8,8,2,2   */
+    int32_t upsample_kernel_sizes[IRIS_HIFIGAN_MAX_STAGES]; /* 16,16,4,4 */
+    int32_t num_kernels;              /* 3   */
+    int32_t resblock_kernel_sizes[IRIS_HIFIGAN_MAX_KERNELS]; /* 3,7,11 */
+    int32_t num_dilations[IRIS_HIFIGAN_MAX_KERNELS];         /* 3,3,3  */
+    int32_t resblock_dilations[IRIS_HIFIGAN_MAX_KERNELS][IRIS_HIFIGAN_MAX_DILATIONS]; /* 1,3,5 each */
+    int32_t pre_kernel_size;          /* 7 (hifigan_pretrained.py:93)  */
+    int32_t post_kernel_size;         /* 7 (hifigan_pretrained.py:120) */
+    float lrelu_slope;                /* 0.1 everywhere (hifigan_pretrained.py:66,68,127,139) */
+} iris_hifigan_config;
+
+typedef struct iris_hifigan_handle iris_hifigan_handle;
+
+/* Per-launch record filled when profiling is enabled (bench.py's roofline leg). */
+typedef struct iris_hifigan_launch_record {
+    int32_t kind;      /* 0 conv_pre, 1 upsample (ConvTranspose1d), 2 MRF ResBlock conv group, 3 conv_post */
+    int32_t stage;     /* upsample stage index, -1 for conv_pre / conv_post */
+    int32_t step;      /* 0..2*num_dilations-1 inside a stage's MRF, else 0 */
+    int32_t reserved;
+    double flops;      /* algorithmic FLOP of this launch (2*MAC, zero padding counted)   */
+    double bytes;      /* algorithmic bytes of this launch, accounting L of SURVEY.md 8d  */
+    float ms;          /* hipEventElapsedTime of this launch on the forward's stream      */
+    float reserved2;
+} iris_hifigan_launch_record;
+
+int32_t iris_hifigan_abi_version(void);
+const char* iris_hifigan_last_error(void);
+
+/* Number of fp32 values iris_hifigan_create expects in `weights_host`: the folded
+ * (weight-norm already applied) tensors of the reference state-dict, concatenated in
+ * this order, each in the reference's own layout:
+ *   conv_pre.weight [C0,in,kpre], conv_pre.bias [C0],
+ *   for i in stages:  ups.i.weight [Cin,Cout,k] (ConvTranspose1d layout), ups.i.bias [Cout],
+ *                     for j in kernels: for m in dilations: convs1.m.weight [C,C,k], convs1.m.bias [C]
+ *                                       for m in dilations: convs2.m.weight [C,C,k], convs2.m.bias [C]
+ *   conv_post.weight [1,Clast,kpost], conv_post.bias [1].                                         */
+int32_t iris_hifigan_weight_count(const iris_hifigan_config* cfg, uint64_t* count);
+
+/* Builds a generator: validates cfg, repacks the weights into MFMA fragment order and
+ * uploads them to the current HIP device. Replaces HiFiGANModel() + load_state_dict
+ * (hifigan_pretrained.py:186-190). */
+int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights_host,
+                            uint64_t n_weights, iris_hifigan_handle** out);
+int32_t iris_hifigan_destroy(iris_hifigan_handle* h);
+
+/* Activation workspace needed by one forward of [B, in_channels, T]. */
+int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, int32_t T,
+                                     int32_t dtype, uint64_t* bytes);
+
+/* mel_dev [B, in_channels, T] fp32 -> wav_dev [B, hop*T] fp32, hop = prod(upsample_rates).
+ * Replaces `self.model(mel_tensor)` (hifigan_pretrained.py:231-232; vocoder.py:200). */
+int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                             void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
+                             int32_t dtype, void* stream);
+
+/* Samples of waveform per mel frame (256 for the V1 config). */
+int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
+
+/* Profiling: when enabled every launch of forward is bracketed by hipEvents on `stream`.
+ * After the stream has been synchronised, read_profile copies up to `capacity` records of the
+ * LAST forward and returns how many launches it had. */
+int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled);
+int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_record* out,
+                                  int32_t capacity, int32_t* n_launches);
+
+/* ---- single-layer entry points (bring-up and parity tests; synchronous, they allocate) ----
+ * x_dev/y_dev/res_dev are channels-last [B, L, C]; weights/bias are HOST arrays in the
+ * reference's layout. in_act: 0 none, 1 LeakyReLU(slope) applied to the input. */
+int32_t iris_hifigan_op_conv1d(const float* x_dev, const float* w_host, const float* bias_host,
+                               const float* res_dev, float* y_dev, int32_t B, int32_t L,
+                               int32_t C_in, int32_t C_out, int32_t k, int32_t dilation,
+                               int32_t in_act, float slope, int32_t x_channels_first, void* stream);
+/* ConvTranspose1d(C_in->C_out, k, stride=u, padding=(k-u)/2), weight [C_in, C_out, k]; y is [B, u*L, C_out]. */
+int32_t iris_hifigan_op_conv_transpose1d(const float* x_dev, const float* w_host,
+                                         const float* bias_host, float* y_dev, int32_t B, int32_t L,
+                                         int32_t C_in, int32_t C_out, int32_t k, int32_t u,
+                                         int32_t in_act, float slope, void* stream);
+/* tanh(Conv1d(C_in->1, k, pad=(k-1)/2)(LeakyReLU((x0+x1+x2)/n_in))): x1/x2 may be NULL (n_in = 1). */
+int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, const float* x2_dev,
+                                  const float* w_host, const float* bias_host, float* y_dev,
+                                  int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
+                                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRIS_HIFIGAN_H */

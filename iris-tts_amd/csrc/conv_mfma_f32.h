@@ -1,0 +1,344 @@
+// conv_mfma_f32.h -- the Conv1d / ConvTranspose1d kernel of the HiFiGAN generator for gfx950.
+//
+// One kernel family covers 77 of the generator's 78 convolutions
+// (reference: HiFiGANModel.forward, src/iris/hifigan_pretrained.py:123-143):
+//   conv_pre           Conv1d(80->512,k7)                       hifigan_pretrained.py:92-94,124
+//   ups[i]             LeakyReLU + ConvTranspose1d              hifigan_pretrained.py:97-109,127-128
+//   resblocks[*]       LeakyReLU + dilated Conv1d (+residual)   hifigan_pretrained.py:64-71
+// (conv_post, C_out = 1, is a sliding dot product: conv_post.h).
+//
+// Formulation.  Activations are channels-last [B, L, C] fp32 in HBM, so one time step is one
+// contiguous, 16-byte aligned row of C floats whatever the halo offset is.  A convolution is the
+// implicit GEMM
+//     Y[t, co] = bias[co] + sum_{kappa, ci} act(X)[t - pad + kappa*dil, ci] * W[co, ci, kappa]
+// with M = time, N = C_out, K = ks * C_in, computed with v_mfma_f32_32x32x2_f32: exact fp32
+// (bitwise an fmaf chain, cdna_hip_programming.md section 3), at the fp32 peak of the chip.
+// A ConvTranspose1d with stride u is u such convolutions ("phases") with ceil(k/u) taps each whose
+// output rows interleave:  o = i*u + phase - p.
+//
+// Work split.  A 256-thread block (4 waves) owns a tile of  (WT*MT*32) time rows x (WC*32) output
+// channels.  The input window (tile + dilated-tap halo) of CIC input channels is staged once into
+// LDS with the input activation applied on the way (LeakyReLU, or the MRF mean of the previous
+// stage followed by LeakyReLU, hifigan_pretrained.py:127,137), then every tap re-reads it at a
+// shifted row: the dilated tap window lives in LDS, HBM sees each input row once per block.
+//   A fragment (time x ci): one ds_read_b128 per 4 MFMAs; row stride CIC+4 floats = 4*odd, which
+//                           makes both the b128 reads and the b128 staging writes conflict-free.
+//   B fragment (ci x co):   one 16-byte global load per 4 MFMAs from weights repacked on the host
+//                           into fragment order (pack_conv1d_weights), served by L2.
+//   Accumulators:           MT tiles of 32x32 (16 VGPRs each).
+// blockIdx.z selects one of up to 8 independent problems of identical shape (the MRF branches of
+// one stage, kernel sizes 3/7/11: three ResBlocks advance in one launch) or the ConvTranspose phase.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace iris {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum InAct : int { IN_ACT_NONE = 0, IN_ACT_LRELU = 1, IN_ACT_MRF_LRELU = 2 };
+
+constexpr int kMaxGroup = 8;
+
+struct ConvProblem {
+    const float* x;     // input  [B, L_in, C_in]   (or [B, C_in, L_in] when x_channels_first)
+    const f32x4* wp;    // packed weights, see pack_conv1d_weights
+    const float* bias;  // [C_out]
+    const float* res;   // residual added in the epilogue [B, L_out, C_out], or nullptr
+    float* y;           // output [B, L_out, C_out]
+    int ks;             // taps
+    int dil;            // dilation (rows between taps)
+    int pad_left;       // input row of tap 0 for output row-index i is  i - pad_left
+    int reserved;
+};
+
+struct ConvLaunch {
+    ConvProblem p[kMaxGroup];
+    const float* xmrf[kMaxGroup];  // in_act == IN_ACT_MRF_LRELU: input = lrelu((xmrf[0]+...)/n_mrf)
+    int n_mrf;
+    int B, L_in, L_out, C_in, C_out;
+    int n_idx;           // number of output row-indices (L_out for conv, L_in + taps - 1 for a phase)
+    int out_stride;      // output row o = i*out_stride + out_off (+ phase)
+    int out_off;
+    int z_is_phase;      // blockIdx.z is a ConvTranspose phase of problem 0 (else a problem index)
+    int64_t phase_wp_stride;  // f32x4 elements between the packed weights of consecutive phases
+    int in_act;
+    int x_channels_first;
+    float slope;
+    int n_co_blk;        // blocks along C_out
+    int Gp;              // padded number of 8-channel groups in the packed weights
+    int n_ct;            // number of 32-wide C_out tiles in the packed weights
+};
+
+__device__ __forceinline__ float lrelu1(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v, float slope) {
+    f32x4 r;
+    r.x = lrelu1(v.x, slope); r.y = lrelu1(v.y, slope);
+    r.z = lrelu1(v.z, slope); r.w = lrelu1(v.w, slope);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage rows [in_row0, in_row0 + R) x channels [c0, c0 + CIC) of the (activated) input into LDS.
+template <int CIC>
+__device__ __forceinline__ void stage_input(const ConvLaunch& a, const ConvProblem& p, float* lds,
+                                            int b, int in_row0, int R, int c0) {
+    constexpr int S = CIC + 4;
+    constexpr int QPR = CIC / 4;  // 16-byte quads per LDS row
+    const int tid = threadIdx.x;
+    const int L_in = a.L_in, C_in = a.C_in;
+    if (!a.x_channels_first && (C_in & 3) == 0) {
+        const int total = R * QPR;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int r = idx / QPR, q = idx - r * QPR;
+            const int row = in_row0 + r, ci = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row >= 0 && row < L_in && ci < C_in) {
+                const size_t off = ((size_t)b * L_in + row) * C_in + ci;
+                if (a.in_act == IN_ACT_MRF_LRELU) {
+                    v = *reinterpret_cast<const f32x4*>(a.xmrf[0] + off);
+                    for (int j = 1; j < a.n_mrf; ++j)
+                        v += *reinterpret_cast<const f32x4*>(a.xmrf[j] + off);
+                    v = v / (float)a.n_mrf;  // true division, hifigan_pretrained.py:137
+                    v = lrelu4(v, a.slope);
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(p.x + off);
+                    if (a.in_act == IN_ACT_LRELU) v = lrelu4(v, a.slope);
+                }
+            }
+            *reinterpret_cast<f32x4*>(lds + r * S + 4 * q) = v;
+        }
+    } else {
+        // scalar path: channels-first input (the mel, hifigan_pretrained.py:228) or C_in % 4 != 0
+        const int total = R * CIC;
+        for (int idx = tid; idx < total; idx += 256) {
+            int r, c;
+            if (a.x_channels_first) { c = idx / R; r = idx - c * R; }   // lanes run along time
+            else                    { r = idx / CIC; c = idx - r * CIC; }
+            const int row = in_row0 + r, ci = c0 + c;
+            float v = 0.f;
+            if (row >= 0 && row < L_in && ci < C_in) {
+                const size_t off = a.x_channels_first ? ((size_t)b * C_in + ci) * L_in + row
+                                                      : ((size_t)b * L_in + row) * C_in + ci;
+                if (a.in_act == IN_ACT_MRF_LRELU) {
+                    v = a.xmrf[0][off];
+                    for (int j = 1; j < a.n_mrf; ++j) v += a.xmrf[j][off];
+                    v = lrelu1(v / (float)a.n_mrf, a.slope);
+                } else {
+                    v = p.x[off];
+                    if (a.in_act == IN_ACT_LRELU) v = lrelu1(v, a.slope);
+                }
+            }
+            lds[r * S + c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KS > 0: taps known at compile time (fully unrolled);  KS == 0: runtime tap count.
+template <int KS, int WT, int WC, int MT, int CIC>
+__device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem& p,
+                                          const f32x4* __restrict__ wp, int out_off, float* lds) {
+    constexpr int S = CIC + 4;
+    constexpr int T_BLK = WT * MT * 32;
+    const int ks = KS > 0 ? KS : p.ks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = wave / WC, wc = wave - wt * WC;
+    const int tile_co = blockIdx.x % a.n_co_blk, tile_t = blockIdx.x / a.n_co_blk;
+    const int b = blockIdx.y;
+    const int i0 = tile_t * T_BLK;
+    const int R = T_BLK + (ks - 1) * p.dil;
+    const int in_row0 = i0 - p.pad_left;
+    const int ct = tile_co * WC + wc;          // this wave's 32-wide C_out tile
+    const bool wave_active = ct < a.n_ct;      // wave-uniform
+    const int lo = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const float* aptr = lds + (wt * MT * 32 + lo) * S + 4 * hi;
+    const f32x4* wlane = wp + (size_t)ct * 64 + lane;
+    const size_t wstep = (size_t)a.n_ct * 64;  // f32x4 elements per (tap, group)
+
+    for (int c0 = 0; c0 < a.C_in; c0 += CIC) {
+        if (c0 > 0) __syncthreads();
+        stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
+        __syncthreads();
+        if (wave_active) {
+            const int g0 = c0 >> 3;
+            auto tap = [&](int kk) {
+                const float* ak = aptr + kk * p.dil * S;
+                const f32x4* wk = wlane + ((size_t)kk * a.Gp + g0) * wstep;
+#pragma unroll
+                for (int g = 0; g < CIC / 8; ++g) {
+                    const f32x4 bw = wk[(size_t)g * wstep];
+                    f32x4 av[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        av[m] = *reinterpret_cast<const f32x4*>(ak + m * 32 * S + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bw[e], acc[m], 0, 0, 0);
+                }
+            };
+            if constexpr (KS > 0) {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) tap(kk);
+            } else {
+                for (int kk = 0; kk < ks; ++kk) tap(kk);
+            }
+        }
+    }
+
+    if (!wave_active) return;
+    // Epilogue. D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int co = ct * 32 + lo;
+    if (co >= a.C_out) return;
+    const float bias = p.bias[co];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + wt * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int o = i * a.out_stride + out_off;
+            if (i < a.n_idx && o >= 0 && o < a.L_out) {
+                const size_t off = ((size_t)b * a.L_out + o) * a.C_out + co;
+                float v = acc[m][r] + bias;
+                if (p.res) v += p.res[off];
+                p.y[off] = v;
+            }
+        }
+    }
+}
+
+template <int WT, int WC, int MT, int CIC>
+__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int z = blockIdx.z;
+    const ConvProblem& p = a.p[a.z_is_phase ? 0 : z];
+    const f32x4* wp = p.wp + (a.z_is_phase ? (int64_t)z * a.phase_wp_stride : 0);
+    const int out_off = a.out_off + (a.z_is_phase ? z : 0);
+    switch (p.ks) {
+        case 2:  conv_body<2,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
+        case 3:  conv_body<3,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
+        case 7:  conv_body<7,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
+        case 11: conv_body<11, WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
+        default: conv_body<0,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: weight repacking into B-fragment order.
+//   packed[((kap*Gp + g)*n_ct + ct)*64 + lane] (an f32x4, component e)
+//       = W[co = ct*32 + (lane&31)][ci = 8g + 4*(lane>>5) + e][kap]      (0 outside C_out/C_in)
+// Gp = groups padded to a multiple of 8 (64 channels) so that any chunking of C_in stays inside.
+inline int packed_groups(int C_in) { return ((C_in + 63) / 64) * 8; }
+inline int packed_cotiles(int C_out) { return (C_out + 31) / 32; }
+inline size_t packed_conv1d_floats(int C_in, int C_out, int ks) {
+    return (size_t)ks * packed_groups(C_in) * packed_cotiles(C_out) * 64 * 4;
+}
+
+// w: reference Conv1d layout [C_out][C_in][ks] (hifigan_pretrained.py:50-57).
+inline void pack_conv1d_weights(const float* w, int C_in, int C_out, int ks, float* out) {
+    const int Gp = packed_groups(C_in), n_ct = packed_cotiles(C_out);
+    for (int kap = 0; kap < ks; ++kap)
+        for (int g = 0; g < Gp; ++g)
+            for (int ct = 0; ct < n_ct; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = ct * 32 + (lane & 31);
+                        const int ci = 8 * g + 4 * (lane >> 5) + e;
+                        float v = 0.f;
+                        if (co < C_out && ci < C_in) v = w[((size_t)co * C_in + ci) * ks + kap];
+                        out[((((size_t)kap * Gp + g) * n_ct + ct) * 64 + lane) * 4 + e] = v;
+                    }
+}
+
+// ConvTranspose1d(C_in->C_out, k, stride u, padding p): weight layout [C_in][C_out][k]
+// (hifigan_pretrained.py:101-107).  Output o gets  sum_m x[i0 - m] * w[:, :, phase + m*u]  with
+// q = o + p, phase = q % u, i0 = q / u.  Phase `ph` is therefore a Conv1d with taps = ceil(k/u),
+// dilation 1, pad_left = taps - 1 and tap kap holding w[:, :, ph + (taps-1-kap)*u].
+inline int convt_taps(int k, int u) { return (k + u - 1) / u; }
+inline size_t packed_convt_phase_floats(int C_in, int C_out, int k, int u) {
+    return packed_conv1d_floats(C_in, C_out, convt_taps(k, u));
+}
+inline void pack_convt_weights(const float* w, int C_in, int C_out, int k, int u, float* out) {
+    const int taps = convt_taps(k, u);
+    const int Gp = packed_groups(C_in), n_ct = packed_cotiles(C_out);
+    const size_t phase_floats = packed_convt_phase_floats(C_in, C_out, k, u);
+    for (int ph = 0; ph < u; ++ph)
+        for (int kap = 0; kap < taps; ++kap) {
+            const int kk = ph + (taps - 1 - kap) * u;  // index into the reference kernel axis
+            for (int g = 0; g < Gp; ++g)
+                for (int ct = 0; ct < n_ct; ++ct)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = ct * 32 + (lane & 31);
+                            const int ci = 8 * g + 4 * (lane >> 5) + e;
+                            float v = 0.f;
+                            if (co < C_out && ci < C_in && kk < k)
+                                v = w[((size_t)ci * C_out + co) * k + kk];
+                            out[ph * phase_floats +
+                                ((((size_t)kap * Gp + g) * n_ct + ct) * 64 + lane) * 4 + e] = v;
+                        }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch: picks the tile shape from C_out / C_in.
+struct ConvTile { int WT, WC, MT, CIC, T_BLK, CO_BLK; };
+
+inline ConvTile pick_tile(int C_in, int C_out) {
+    ConvTile t;
+    t.MT = 2;
+    if (C_out <= 32)      { t.WT = 4; t.WC = 1; }
+    else if (C_out <= 64) { t.WT = 2; t.WC = 2; }
+    else                  { t.WT = 1; t.WC = 4; }
+    t.CIC = (C_in <= 32 && t.WC == 1) ? 32 : 64;
+    t.T_BLK = t.WT * t.MT * 32;
+    t.CO_BLK = t.WC * 32;
+    return t;
+}
+
+// Fills the derived fields of `a` (n_co_blk, Gp, n_ct) and launches. `nz` = problems or phases.
+inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
+    const ConvTile t = pick_tile(a.C_in, a.C_out);
+    a.n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
+    a.Gp = packed_groups(a.C_in);
+    a.n_ct = packed_cotiles(a.C_out);
+    int span = 0;
+    const int np = a.z_is_phase ? 1 : nz;
+    for (int j = 0; j < np; ++j) {
+        const int s = (a.p[j].ks - 1) * a.p[j].dil;
+        if (s > span) span = s;
+    }
+    const size_t lds_bytes = (size_t)(t.T_BLK + span) * (t.CIC + 4) * sizeof(float);
+    const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
+    dim3 grid((unsigned)(n_t * a.n_co_blk), (unsigned)a.B, (unsigned)nz), block(256);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+#define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
+    do {                                                                                          \
+        auto kfn = conv_mfma_f32_kernel<WT_, WC_, 2, CIC_>;                                       \
+        if (lds_bytes > 64 * 1024) {                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               (int)lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+    } while (0)
+    if (t.WT == 4 && t.CIC == 32)      IRIS_LAUNCH(4, 1, 32);
+    else if (t.WT == 4)                IRIS_LAUNCH(4, 1, 64);
+    else if (t.WT == 2)                IRIS_LAUNCH(2, 2, 64);
+    else                               IRIS_LAUNCH(1, 4, 64);
+#undef IRIS_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace iris

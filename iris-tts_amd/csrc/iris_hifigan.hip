@@ -1,0 +1,556 @@
+// iris_hifigan.hip -- C-ABI (include/iris_hifigan.h) over the gfx950 kernels.
+//
+// Generator dataflow follows HiFiGANModel.forward (reference src/iris/hifigan_pretrained.py:123-143,
+// Keras twin src/iris/vocoder.py:103-130):
+//   conv_pre -> for each stage { LeakyReLU -> ConvTranspose1d -> MRF(3 ResBlocks) / 3 } -> LeakyReLU
+//   -> conv_post -> tanh.
+// Launch plan for one forward (V1 config: 31 launches):
+//   1            conv_pre, reading the channels-first mel directly
+//   per stage:   1 upsample launch (all u phases as blockIdx.z; input = LeakyReLU of conv_pre, or
+//                LeakyReLU(mean of the previous stage's branch outputs) fused into the LDS staging)
+//                2*num_dilations grouped launches: launch s runs conv (s even: convs1[s/2], dilated;
+//                s odd: convs2[s/2] + residual) of ALL MRF branches at once (blockIdx.z = branch)
+//   1            conv_post + tanh, reading the mean of the last stage's branch outputs.
+// The MRF sum and the division by num_kernels (hifigan_pretrained.py:131-137) are never
+// materialised: the consumer of a stage reads the branch outputs and forms ((b0+b1)+b2)/3 itself.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/iris_hifigan.h"
+#include "conv_mfma_f32.h"
+#include "conv_post.h"
+
+using namespace iris;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(IRIS_HIFIGAN_HIP_ERROR, "%s failed: %s (%s:%d)", #expr,              \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                         \
+    } while (0)
+
+struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on the device
+    int kind = 0;                                     // 0 Conv1d, 1 ConvTranspose1d, 2 conv_post
+    int C_in = 0, C_out = 0, k = 0, dil = 1, u = 1;  // u = stride of a ConvTranspose1d
+    size_t w_off = 0, b_off = 0;                      // float offsets into the device blob
+    size_t w_floats = 0;                              // packed size
+    size_t ref_w_floats = 0;                          // size in the reference layout
+};
+
+struct Stage {
+    ConvLayer up;
+    int C = 0;             // channels after the upsample
+    int rate = 1;
+    // convs[j][m][0|1] = resblocks[i*nk + j].convs{1,2}[m]
+    std::vector<std::vector<ConvLayer>> c1, c2;
+};
+
+}  // namespace
+
+struct iris_hifigan_handle {
+    iris_hifigan_config cfg;
+    ConvLayer pre, post;
+    std::vector<Stage> stages;
+    float* blob = nullptr;   // device: packed weights + biases
+    size_t blob_floats = 0;
+    int hop = 1;
+    int device = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<iris_hifigan_launch_record> recs;
+    int n_rec = 0;
+};
+
+namespace {
+
+int validate(const iris_hifigan_config* c) {
+    if (!c) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "config is NULL");
+    if (c->in_channels < 1 || c->upsample_initial_channel < 1)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "channel counts must be positive");
+    if (c->num_upsamples < 1 || c->num_upsamples > IRIS_HIFIGAN_MAX_STAGES)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "num_upsamples %d out of range", c->num_upsamples);
+    if (c->num_kernels < 1 || c->num_kernels > IRIS_HIFIGAN_MAX_KERNELS)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "num_kernels %d out of range", c->num_kernels);
+    if ((c->upsample_initial_channel >> c->num_upsamples) < 1)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "upsample_initial_channel too small for %d stages",
+                    c->num_upsamples);
+    for (int i = 0; i < c->num_upsamples; ++i) {
+        const int u = c->upsample_rates[i], k = c->upsample_kernel_sizes[i];
+        if (u < 1 || k < u || ((k - u) & 1))
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT,
+                        "stage %d: need kernel >= rate and (kernel - rate) even, got k=%d u=%d", i, k, u);
+        if (u > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "upsample rate too large");
+    }
+    for (int j = 0; j < c->num_kernels; ++j) {
+        const int k = c->resblock_kernel_sizes[j];
+        if (k < 1 || !(k & 1))
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "resblock kernel size %d must be odd", k);
+        if (c->num_dilations[j] < 1 || c->num_dilations[j] > IRIS_HIFIGAN_MAX_DILATIONS)
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "num_dilations[%d] out of range", j);
+        if (c->num_dilations[j] != c->num_dilations[0])
+            return fail(IRIS_HIFIGAN_UNSUPPORTED, "MRF branches must have the same number of dilations");
+        for (int m = 0; m < c->num_dilations[j]; ++m)
+            if (c->resblock_dilations[j][m] < 1)
+                return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "dilations must be >= 1");
+    }
+    if (c->pre_kernel_size < 1 || !(c->pre_kernel_size & 1) || c->post_kernel_size < 1 ||
+        !(c->post_kernel_size & 1))
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "pre/post kernel sizes must be odd");
+    return IRIS_HIFIGAN_OK;
+}
+
+// Walks the layers in blob order; fn(layer&) for each.
+template <class Fn>
+void for_each_layer(iris_hifigan_handle* h, Fn fn) {
+    fn(h->pre);
+    for (auto& st : h->stages) {
+        fn(st.up);
+        for (size_t j = 0; j < st.c1.size(); ++j) {
+            for (auto& l : st.c1[j]) fn(l);
+            for (auto& l : st.c2[j]) fn(l);
+        }
+    }
+    fn(h->post);
+}
+
+void build_layers(iris_hifigan_handle* h) {
+    const iris_hifigan_config& c = h->cfg;
+    h->pre.kind = 0;
+    h->pre.C_in = c.in_channels; h->pre.C_out = c.upsample_initial_channel; h->pre.k = c.pre_kernel_size;
+    h->stages.resize(c.num_upsamples);
+    h->hop = 1;
+    int ch = c.upsample_initial_channel;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        Stage& st = h->stages[i];
+        st.up.kind = 1;
+        st.up.C_in = ch; st.up.C_out = ch / 2; st.up.k = c.upsample_kernel_sizes[i];
+        st.up.u = c.upsample_rates[i];
+        st.rate = st.up.u;
+        ch /= 2;
+        st.C = ch;
+        h->hop *= st.rate;
+        st.c1.resize(c.num_kernels); st.c2.resize(c.num_kernels);
+        for (int j = 0; j < c.num_kernels; ++j) {
+            for (int m = 0; m < c.num_dilations[j]; ++m) {
+                ConvLayer l1; l1.C_in = ch; l1.C_out = ch; l1.k = c.resblock_kernel_sizes[j];
+                l1.dil = c.resblock_dilations[j][m];
+                ConvLayer l2 = l1; l2.dil = 1;
+                st.c1[j].push_back(l1); st.c2[j].push_back(l2);
+            }
+        }
+    }
+    h->post.kind = 2;
+    h->post.C_in = ch; h->post.C_out = 1; h->post.k = c.post_kernel_size;
+    // device blob layout
+    size_t off = 0;
+    for_each_layer(h, [&](ConvLayer& l) {
+        l.ref_w_floats = (size_t)l.C_in * l.C_out * l.k;
+        if (l.kind == 2)      l.w_floats = (size_t)l.k * l.C_in;
+        else if (l.kind == 1) l.w_floats = packed_convt_phase_floats(l.C_in, l.C_out, l.k, l.u) * l.u;
+        else                  l.w_floats = packed_conv1d_floats(l.C_in, l.C_out, l.k);
+    });
+    for_each_layer(h, [&](ConvLayer& l) {
+        l.w_off = off; off += (l.w_floats + 3) & ~(size_t)3;
+        l.b_off = off; off += ((size_t)l.C_out + 3) & ~(size_t)3;
+    });
+    h->blob_floats = off;
+}
+
+uint64_t ref_weight_count(iris_hifigan_handle* h) {
+    uint64_t n = 0;
+    for_each_layer(h, [&](ConvLayer& l) { n += l.ref_w_floats + l.C_out; });
+    return n;
+}
+
+// ---- workspace layout (floats per mel frame, times B*T) ----
+struct WsLayout {
+    size_t pre;   // conv_pre output                [B, T, C0]
+    size_t up;    // upsample output of a stage     [B, L, C]     (max over stages)
+    size_t y[IRIS_HIFIGAN_MAX_KERNELS];   // running x of branch j
+    size_t xt[IRIS_HIFIGAN_MAX_KERNELS];  // conv1 output of branch j
+    size_t total; // floats
+};
+
+WsLayout ws_layout(const iris_hifigan_handle* h, int B, int T) {
+    WsLayout w;
+    const size_t frames = (size_t)B * T;
+    size_t per_frame_max = 0;
+    size_t L = 1;
+    for (const auto& st : h->stages) {
+        L *= st.rate;
+        const size_t e = L * st.C;
+        if (e > per_frame_max) per_frame_max = e;
+    }
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += (floats + 63) & ~(size_t)63; return o; };
+    w.pre = take(frames * h->pre.C_out);
+    w.up = take(frames * per_frame_max);
+    for (int j = 0; j < h->cfg.num_kernels; ++j) {
+        w.y[j] = take(frames * per_frame_max);
+        w.xt[j] = take(frames * per_frame_max);
+    }
+    w.total = off;
+    return w;
+}
+
+struct Prof {
+    iris_hifigan_handle* h;
+    hipStream_t stream;
+    int idx = 0;
+    int begin(int kind, int stage, int step, double flops, double bytes) {
+        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        if ((size_t)(2 * idx + 2) > h->ev.size()) {
+            const size_t old = h->ev.size();
+            h->ev.resize(2 * idx + 2);
+            for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+        }
+        if ((size_t)idx >= h->recs.size()) h->recs.resize(idx + 1);
+        iris_hifigan_launch_record& r = h->recs[idx];
+        memset(&r, 0, sizeof(r));
+        r.kind = kind; r.stage = stage; r.step = step; r.flops = flops; r.bytes = bytes;
+        HIP_TRY(hipEventRecord(h->ev[2 * idx], stream));
+        return IRIS_HIFIGAN_OK;
+    }
+    int end() {
+        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        HIP_TRY(hipEventRecord(h->ev[2 * idx + 1], stream));
+        ++idx;
+        return IRIS_HIFIGAN_OK;
+    }
+};
+
+#define TRY(expr) do { int rc__ = (expr); if (rc__ != IRIS_HIFIGAN_OK) return rc__; } while (0)
+
+void init_launch(ConvLaunch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t iris_hifigan_abi_version(void) { return IRIS_HIFIGAN_ABI_VERSION; }
+const char* iris_hifigan_last_error(void) { return g_err; }
+
+int32_t iris_hifigan_weight_count(const iris_hifigan_config* cfg, uint64_t* count) {
+    TRY(validate(cfg));
+    if (!count) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "count is NULL");
+    iris_hifigan_handle tmp;
+    tmp.cfg = *cfg;
+    build_layers(&tmp);
+    *count = ref_weight_count(&tmp);
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights_host,
+                            uint64_t n_weights, iris_hifigan_handle** out) {
+    TRY(validate(cfg));
+    if (!weights_host || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    iris_hifigan_handle* h = new (std::nothrow) iris_hifigan_handle;
+    if (!h) return fail(IRIS_HIFIGAN_OUT_OF_MEMORY, "host allocation failed");
+    h->cfg = *cfg;
+    build_layers(h);
+    const uint64_t expect = ref_weight_count(h);
+    if (n_weights != expect) {
+        delete h;
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "weight blob has %llu values, config needs %llu",
+                    (unsigned long long)n_weights, (unsigned long long)expect);
+    }
+    std::vector<float> host(h->blob_floats, 0.f);
+    const float* src = weights_host;
+    for_each_layer(h, [&](ConvLayer& l) {
+        float* dst = host.data() + l.w_off;
+        if (l.kind == 2) {
+            // [1][C][k] -> [k][C]
+            for (int c = 0; c < l.C_in; ++c)
+                for (int kap = 0; kap < l.k; ++kap) dst[(size_t)kap * l.C_in + c] = src[(size_t)c * l.k + kap];
+        } else if (l.kind == 1) {
+            pack_convt_weights(src, l.C_in, l.C_out, l.k, l.u, dst);
+        } else {
+            pack_conv1d_weights(src, l.C_in, l.C_out, l.k, dst);
+        }
+        src += l.ref_w_floats;
+        memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
+        src += l.C_out;
+    });
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess) e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->blob) (void)hipFree(h->blob);
+        delete h;
+        return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
+                    "weight upload failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
+    if (!h) return IRIS_HIFIGAN_OK;
+    for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop) {
+    if (!h || !hop) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    *hop = h->hop;
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, int32_t T,
+                                     int32_t dtype, uint64_t* bytes) {
+    if (!h || !bytes) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    *bytes = ws_layout(h, B, T).total * sizeof(float);
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled) {
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    h->profiling = enabled != 0;
+    h->n_rec = 0;
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_record* out,
+                                  int32_t capacity, int32_t* n_launches) {
+    if (!h || !n_launches) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    *n_launches = h->n_rec;
+    for (int i = 0; i < h->n_rec; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        h->recs[i].ms = ms;
+        if (out && i < capacity) out[i] = h->recs[i];
+    }
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                             void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
+                             int32_t dtype, void* stream_) {
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    if (B == 0 || T == 0) { h->n_rec = 0; return IRIS_HIFIGAN_OK; }  // empty batch / empty mel -> empty waveform
+    if (!mel_dev || !wav_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
+    if (B > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "batch %d exceeds 65535 (grid.y)", B);
+    if ((int64_t)T * h->hop > (int64_t)1 << 30)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "T*hop = %lld exceeds 2^30 rows", (long long)T * h->hop);
+    const WsLayout w = ws_layout(h, B, T);
+    if (workspace_bytes < w.total * sizeof(float))
+        return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
+                    (unsigned long long)workspace_bytes, (unsigned long long)(w.total * sizeof(float)));
+    hipStream_t stream = (hipStream_t)stream_;
+    float* ws = (float*)workspace_dev;
+    const float* blob = h->blob;
+    const float slope = h->cfg.lrelu_slope;
+    const int nk = h->cfg.num_kernels;
+    Prof prof{h, stream};
+    const double fB = (double)B;
+
+    // ---- conv_pre (hifigan_pretrained.py:124) ----
+    {
+        ConvLaunch a; init_launch(a);
+        const ConvLayer& l = h->pre;
+        a.p[0].x = (const float*)mel_dev; a.p[0].wp = (const f32x4*)(blob + l.w_off);
+        a.p[0].bias = blob + l.b_off; a.p[0].res = nullptr; a.p[0].y = ws + w.pre;
+        a.p[0].ks = l.k; a.p[0].dil = 1; a.p[0].pad_left = (l.k - 1) / 2;
+        a.B = B; a.L_in = T; a.L_out = T; a.C_in = l.C_in; a.C_out = l.C_out; a.n_idx = T;
+        a.in_act = IN_ACT_NONE; a.x_channels_first = 1; a.slope = slope;
+        TRY(prof.begin(0, -1, 0, 2.0 * fB * T * l.C_in * l.C_out * l.k,
+                       4.0 * (fB * T * (l.C_in + l.C_out) + (double)l.ref_w_floats + l.C_out)));
+        HIP_TRY(launch_conv(a, 1, stream));
+        TRY(prof.end());
+    }
+
+    int L = T;
+    for (size_t i = 0; i < h->stages.size(); ++i) {
+        const Stage& st = h->stages[i];
+        const int L_out = L * st.rate;
+        // ---- LeakyReLU + ConvTranspose1d (hifigan_pretrained.py:127-128) ----
+        {
+            ConvLaunch a; init_launch(a);
+            const ConvLayer& l = st.up;
+            const int taps = convt_taps(l.k, l.u);
+            a.p[0].wp = (const f32x4*)(blob + l.w_off); a.p[0].bias = blob + l.b_off;
+            a.p[0].res = nullptr; a.p[0].y = ws + w.up;
+            a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
+            int n_in = 1;
+            if (i == 0) { a.p[0].x = ws + w.pre; a.in_act = IN_ACT_LRELU; }
+            else {
+                a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk; n_in = nk;
+                for (int j = 0; j < nk; ++j) a.xmrf[j] = ws + w.y[j];
+                a.p[0].x = a.xmrf[0];
+            }
+            a.B = B; a.L_in = L; a.L_out = L_out; a.C_in = l.C_in; a.C_out = l.C_out;
+            a.n_idx = L + taps - 1; a.out_stride = l.u; a.out_off = -(l.k - l.u) / 2;
+            a.z_is_phase = 1;
+            a.phase_wp_stride = (int64_t)(packed_convt_phase_floats(l.C_in, l.C_out, l.k, l.u) / 4);
+            a.slope = slope;
+            TRY(prof.begin(1, (int)i, 0, 2.0 * fB * L * l.C_in * l.C_out * l.k,
+                           4.0 * (fB * L * l.C_in * n_in + fB * L_out * l.C_out +
+                                  (double)l.ref_w_floats + l.C_out)));
+            HIP_TRY(launch_conv(a, l.u, stream));
+            TRY(prof.end());
+        }
+        // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----
+        const int nd = h->cfg.num_dilations[0];
+        const double n_el = fB * L_out * st.C;
+        for (int m = 0; m < nd; ++m) {
+            for (int half = 0; half < 2; ++half) {
+                ConvLaunch a; init_launch(a);
+                double flops = 0, wbytes = 0;
+                for (int j = 0; j < nk; ++j) {
+                    const ConvLayer& l = half == 0 ? st.c1[j][m] : st.c2[j][m];
+                    ConvProblem& p = a.p[j];
+                    const float* cur = (m == 0) ? ws + w.up : ws + w.y[j];  // x entering this pair
+                    if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
+                    else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
+                    p.wp = (const f32x4*)(blob + l.w_off); p.bias = blob + l.b_off;
+                    p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
+                    flops += 2.0 * n_el * l.C_in * l.k;
+                    wbytes += 4.0 * ((double)l.ref_w_floats + l.C_out);
+                }
+                a.B = B; a.L_in = L_out; a.L_out = L_out; a.C_in = st.C; a.C_out = st.C;
+                a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
+                TRY(prof.begin(2, (int)i, 2 * m + half, flops,
+                               4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
+                HIP_TRY(launch_conv(a, nk, stream));
+                TRY(prof.end());
+            }
+        }
+        L = L_out;
+    }
+
+    // ---- LeakyReLU + conv_post + tanh (hifigan_pretrained.py:139-141) ----
+    {
+        ConvPostLaunch a; memset(&a, 0, sizeof(a));
+        const ConvLayer& l = h->post;
+        for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+        a.n_in = nk; a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
+        a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope;
+        TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
+                       4.0 * (fB * L * l.C_in * nk + fB * L + (double)l.ref_w_floats + 1)));
+        HIP_TRY(launch_conv_post(a, stream));
+        TRY(prof.end());
+    }
+    h->n_rec = prof.idx;
+    return IRIS_HIFIGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-layer entry points
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    float* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t upload(const std::vector<float>& v) {
+        hipError_t e = hipMalloc(&p, v.size() * sizeof(float));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+};
+}  // namespace
+
+int32_t iris_hifigan_op_conv1d(const float* x_dev, const float* w_host, const float* bias_host,
+                               const float* res_dev, float* y_dev, int32_t B, int32_t L,
+                               int32_t C_in, int32_t C_out, int32_t k, int32_t dilation,
+                               int32_t in_act, float slope, int32_t x_channels_first, void* stream_) {
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || k < 1 || !(k & 1) || dilation < 1 || B > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv1d shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<float> packed(packed_conv1d_floats(C_in, C_out, k) + C_out);
+    pack_conv1d_weights(w_host, C_in, C_out, k, packed.data());
+    const size_t boff = packed.size() - C_out;
+    memcpy(packed.data() + boff, bias_host, sizeof(float) * C_out);
+    DevBuf wb;
+    HIP_TRY(wb.upload(packed));
+    ConvLaunch a; init_launch(a);
+    a.p[0].x = x_dev; a.p[0].wp = (const f32x4*)wb.p; a.p[0].bias = wb.p + boff; a.p[0].res = res_dev;
+    a.p[0].y = y_dev; a.p[0].ks = k; a.p[0].dil = dilation; a.p[0].pad_left = dilation * (k - 1) / 2;
+    a.B = B; a.L_in = L; a.L_out = L; a.C_in = C_in; a.C_out = C_out; a.n_idx = L;
+    a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.x_channels_first = x_channels_first; a.slope = slope;
+    HIP_TRY(launch_conv(a, 1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_conv_transpose1d(const float* x_dev, const float* w_host,
+                                         const float* bias_host, float* y_dev, int32_t B, int32_t L,
+                                         int32_t C_in, int32_t C_out, int32_t k, int32_t u,
+                                         int32_t in_act, float slope, void* stream_) {
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || u < 1 || k < u || ((k - u) & 1) || B > 65535 || u > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_transpose1d shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t phase_floats = packed_convt_phase_floats(C_in, C_out, k, u);
+    std::vector<float> packed(phase_floats * u + C_out);
+    pack_convt_weights(w_host, C_in, C_out, k, u, packed.data());
+    const size_t boff = packed.size() - C_out;
+    memcpy(packed.data() + boff, bias_host, sizeof(float) * C_out);
+    DevBuf wb;
+    HIP_TRY(wb.upload(packed));
+    const int taps = convt_taps(k, u);
+    ConvLaunch a; init_launch(a);
+    a.p[0].x = x_dev; a.p[0].wp = (const f32x4*)wb.p; a.p[0].bias = wb.p + boff; a.p[0].res = nullptr;
+    a.p[0].y = y_dev; a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
+    a.B = B; a.L_in = L; a.L_out = L * u; a.C_in = C_in; a.C_out = C_out; a.n_idx = L + taps - 1;
+    a.out_stride = u; a.out_off = -(k - u) / 2; a.z_is_phase = 1;
+    a.phase_wp_stride = (int64_t)(phase_floats / 4);
+    a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
+    HIP_TRY(launch_conv(a, u, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, const float* x2_dev,
+                                  const float* w_host, const float* bias_host, float* y_dev,
+                                  int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
+                                  void* stream_) {
+    if (!x0_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || k < 1 || !(k & 1) || B > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_post shape");
+    if ((x1_dev == nullptr) != (x2_dev == nullptr))
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "x1 and x2 must both be given or both be NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<float> wv((size_t)k * C_in + 1);
+    for (int c = 0; c < C_in; ++c)
+        for (int kap = 0; kap < k; ++kap) wv[(size_t)kap * C_in + c] = w_host[(size_t)c * k + kap];
+    wv[(size_t)k * C_in] = bias_host[0];
+    DevBuf wb;
+    HIP_TRY(wb.upload(wv));
+    ConvPostLaunch a; memset(&a, 0, sizeof(a));
+    a.x[0] = x0_dev; a.n_in = 1;
+    if (x1_dev) { a.x[1] = x1_dev; a.x[2] = x2_dev; a.n_in = 3; }
+    a.w = wb.p; a.bias = wb.p + (size_t)k * C_in; a.y = y_dev;
+    a.B = B; a.L = L; a.C = C_in; a.k = k; a.slope = slope;
+    HIP_TRY(launch_conv_post(a, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+}  // extern "C"

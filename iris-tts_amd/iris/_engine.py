@@ -1,0 +1,153 @@
+"""Device-side generator: owns the native handle and the activation workspace.
+
+PyTorch-ROCm is used here for device memory and streams only (``torch.empty``, ``data_ptr()``,
+``torch.cuda.current_stream()``); all arithmetic happens in the HIP library behind the C-ABI.
+This object replaces ``self.model(mel_tensor)`` of the reference
+(src/iris/hifigan_pretrained.py:231-232, src/iris/vocoder.py:200).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from ._weights import GeneratorConfig, expected_weight_count, weight_blob
+
+KIND_NAMES = {0: "conv_pre", 1: "upsample", 2: "mrf_resblock_conv", 3: "conv_post"}
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "iris vocoder (MI355X build): no HIP device is visible. This build has no CPU path; "
+            "run on a gfx950 GPU.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class GeneratorEngine:
+    """One HiFiGAN generator resident on one GPU."""
+
+    def __init__(self, cfg: GeneratorConfig, state_dict: Mapping[str, object],
+                 device: Optional[torch.device] = None):
+        self.cfg = cfg
+        self.lib = _native.load()
+        self.device = device if device is not None else require_gpu()
+        if self.device.type != "cuda":
+            raise RuntimeError(f"GeneratorEngine needs a HIP device, got {self.device}")
+        blob = weight_blob(cfg, state_dict)
+        assert blob.size == expected_weight_count(cfg)
+        self._handle = ctypes.c_void_p()
+        ccfg = _native.make_config(cfg)
+        with torch.cuda.device(self.device):
+            _native.check("iris_hifigan_create", self.lib.iris_hifigan_create(
+                ctypes.byref(ccfg), blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                ctypes.c_uint64(blob.size), ctypes.byref(self._handle)))
+        hop = ctypes.c_int32()
+        _native.check("iris_hifigan_hop_length", self.lib.iris_hifigan_hop_length(self._handle, ctypes.byref(hop)))
+        self.hop_length = int(hop.value)
+        self._workspace: Optional[torch.Tensor] = None
+
+    # -- lifetime ----------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self.lib.iris_hifigan_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+        self._workspace = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- forward -----------------------------------------------------------------------------
+    def workspace_bytes(self, batch: int, frames: int) -> int:
+        n = ctypes.c_uint64()
+        _native.check("iris_hifigan_workspace_bytes", self.lib.iris_hifigan_workspace_bytes(
+            self._handle, batch, frames, _native.DTYPE_F32, ctypes.byref(n)))
+        return int(n.value)
+
+    def _get_workspace(self, nbytes: int) -> torch.Tensor:
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None  # release before growing
+            self._workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mel: fp32 device tensor [B, in_channels, T] -> waveform fp32 [B, hop*T] (asynchronous on
+        the current stream)."""
+        if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
+            raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
+        if mel.device != self.device:
+            raise ValueError(f"mel is on {mel.device}, engine on {self.device}")
+        mel = mel.to(torch.float32).contiguous()
+        batch, _, frames = mel.shape
+        if out is None:
+            out = torch.empty((batch, frames * self.hop_length), dtype=torch.float32, device=self.device)
+        elif out.shape != (batch, frames * self.hop_length) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 tensor [B, hop*T]")
+        if batch == 0 or frames == 0:
+            return out
+        nbytes = self.workspace_bytes(batch, frames)
+        ws = self._get_workspace(nbytes)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check("iris_hifigan_forward", self.lib.iris_hifigan_forward(
+            self._handle, ctypes.c_void_p(mel.data_ptr()), batch, frames, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(ws.data_ptr()), ctypes.c_uint64(ws.numel()), _native.DTYPE_F32,
+            ctypes.c_void_p(stream)))
+        return out
+
+    __call__ = forward
+
+    # -- profiling (bench.py roofline leg) -----------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        _native.check("iris_hifigan_set_profiling", self.lib.iris_hifigan_set_profiling(self._handle, int(enabled)))
+
+    def read_profile(self) -> List[dict]:
+        """Per-launch records of the last forward; the stream must have been synchronised."""
+        n = ctypes.c_int32()
+        cap = 1024
+        recs = (_native.LaunchRecord * cap)()
+        _native.check("iris_hifigan_read_profile", self.lib.iris_hifigan_read_profile(
+            self._handle, recs, cap, ctypes.byref(n)))
+        out = []
+        for i in range(min(n.value, cap)):
+            r = recs[i]
+            out.append({"kind": KIND_NAMES.get(r.kind, str(r.kind)), "stage": r.stage, "step": r.step,
+                        "flops": r.flops, "bytes": r.bytes, "ms": r.ms})
+        return out
+
+
+def algorithmic_work(cfg: GeneratorConfig) -> dict:
+    """FLOP and bytes (accounting L) per mel frame for cfg.  For the V1
+    config: 614,105,088 FLOP and 1,305,936 activation elements per frame."""
+    from ._weights import layer_specs
+
+    specs = layer_specs(cfg)
+    mac = 0
+    elems = 0
+    length = 1  # time positions per frame at the current layer input
+    nk = cfg.num_kernels
+    for s in specs:
+        if s.kind == "conv" and s.name == "conv_pre":
+            mac += s.c_in * s.c_out * s.k
+            elems += s.c_in + s.c_out
+        elif s.kind == "convt":
+            mac += length * s.c_in * s.c_out * s.k
+            stage = int(s.name.split(".")[1])
+            n_in = 1 if stage == 0 else nk
+            elems += length * s.c_in * n_in + length * s.stride * s.c_out
+            length *= s.stride
+        elif s.kind == "conv":
+            mac += length * s.c_in * s.c_out * s.k
+            n = length * s.c_out
+            elems += 2 * n if ".convs1." in s.name else 3 * n
+        else:  # post
+            mac += length * s.c_in * s.k
+            elems += length * s.c_in * nk + length
+    weights = expected_weight_count(cfg)
+    return {"flop_per_frame": 2 * mac, "mac_per_frame": mac, "elements_per_frame": elems,
+            "weight_values": weights, "hop_length": cfg.hop_length}

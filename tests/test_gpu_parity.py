@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the reference's goldens.
+
+Needs a real MI355X: every test is marked ``gpu``.  Tolerance: BASELINE.json's north_star states
+<= 1e-4 max-abs against the reference fp32 generator for the waveform; single layers are held to a
+relative 2e-5 of the layer's output scale (fp32 fmaf chains vs ATen/fp64: pure rounding noise).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_config
+from oracle import hifigan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_WAV = 1e-4      # north_star
+TOL_LAYER = 2e-5    # relative to max|reference output| of the layer
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from iris import _native
+    return _native.load()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _cl(x_cf):  # [B,C,L] numpy -> channels-last device tensor [B,L,C]
+    return torch.from_numpy(np.ascontiguousarray(x_cf.transpose(0, 2, 1))).cuda()
+
+
+def _check(fn, status):
+    from iris import _native
+    _native.check(fn, status)
+
+
+# ------------------------------------------------------------------------------------------------
+# single layers
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # (B, L, C_in, C_out, k, d, act, residual)      -- the V1 shapes of every tile config ...
+    (1, 300, 32, 32, 3, 1, 1, True), (2, 517, 32, 32, 11, 5, 1, False), (1, 260, 32, 32, 7, 3, 1, True),
+    (1, 200, 64, 64, 11, 5, 1, True), (2, 131, 64, 64, 3, 3, 1, False),
+    (1, 130, 128, 128, 7, 5, 1, True), (1, 70, 256, 256, 11, 3, 1, True), (1, 64, 256, 256, 3, 1, 1, False),
+    (2, 33, 80, 512, 7, 1, 0, False),          # conv_pre shape
+    # ... and ragged ones: channels not multiples of 8/4, generic tap count, tiny length
+    (1, 5, 32, 32, 11, 5, 1, True), (3, 41, 24, 24, 5, 2, 1, True), (1, 77, 6, 6, 5, 6, 1, True),
+    (1, 50, 12, 40, 9, 1, 0, False), (1, 1, 32, 32, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("B,L,Ci,Co,k,d,act,use_res", CONV_CASES)
+def test_conv1d_matches_oracle(lib, B, L, Ci, Co, k, d, act, use_res):
+    rng = np.random.default_rng(B * 1000 + L + Ci + k + d)
+    x = rng.standard_normal((B, Ci, L)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, k)) / np.sqrt(Ci * k)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    res = rng.standard_normal((B, Co, L)).astype(np.float32) if use_res else None
+    xin = orc.lrelu_np(x, 0.1) if act else x
+    want = orc.conv1d_np(xin, w, b, d)
+    if use_res:
+        want = want + res
+    xd = _cl(x)
+    rd = _cl(res) if use_res else None
+    yd = torch.full((B, L, Co), float("nan"), device="cuda")
+    _check("op_conv1d", lib.iris_hifigan_op_conv1d(
+        xd.data_ptr(), _fp(w), _fp(b), rd.data_ptr() if use_res else None, yd.data_ptr(),
+        B, L, Ci, Co, k, d, act, 0.1, 0, None))
+    got = yd.cpu().numpy().transpose(0, 2, 1)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max())
+
+
+def test_conv1d_channels_first_input(lib):
+    """conv_pre reads the mel in the reference's own layout [B, 80, T] (hifigan_pretrained.py:228)."""
+    rng = np.random.default_rng(11)
+    B, L, Ci, Co, k = 2, 45, 80, 512, 7
+    x = rng.standard_normal((B, Ci, L)).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, k)) / np.sqrt(Ci * k)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    want = orc.conv1d_np(x, w, b, 1)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((B, L, Co), float("nan"), device="cuda")
+    _check("op_conv1d", lib.iris_hifigan_op_conv1d(xd.data_ptr(), _fp(w), _fp(b), None, yd.data_ptr(),
+                                                   B, L, Ci, Co, k, 1, 0, 0.1, 1, None))
+    got = yd.cpu().numpy().transpose(0, 2, 1)
+    assert np.abs(got - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max())
+
+
+CONVT_CASES = [
+    # (B, L, C_in, C_out, k, u) -- the four V1 upsamplers, then ragged ones
+    (1, 37, 512, 256, 16, 8), (2, 65, 256, 128, 16, 8), (1, 130, 128, 64, 4, 2), (1, 300, 64, 32, 4, 2),
+    (1, 19, 48, 24, 8, 4), (2, 20, 12, 6, 9, 3), (1, 1, 64, 32, 4, 2), (1, 7, 24, 12, 4, 2), (1, 9, 16, 8, 2, 2),
+]
+
+
+@pytest.mark.parametrize("B,L,Ci,Co,k,u", CONVT_CASES)
+def test_conv_transpose1d_matches_oracle(lib, B, L, Ci, Co, k, u):
+    rng = np.random.default_rng(L * 7 + Ci + k)
+    x = rng.standard_normal((B, Ci, L)).astype(np.float32)
+    w = (rng.standard_normal((Ci, Co, k)) / np.sqrt(Ci * k / u)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    want = orc.conv_transpose1d_np(orc.lrelu_np(x, 0.1), w, b, u, (k - u) // 2)
+    xd = _cl(x)
+    yd = torch.full((B, L * u, Co), float("nan"), device="cuda")
+    _check("op_conv_transpose1d", lib.iris_hifigan_op_conv_transpose1d(
+        xd.data_ptr(), _fp(w), _fp(b), yd.data_ptr(), B, L, Ci, Co, k, u, 1, 0.1, None))
+    got = yd.cpu().numpy().transpose(0, 2, 1)
+    assert got.shape == want.shape
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("B,L,C,k,three", [(1, 700, 32, 7, True), (2, 300, 32, 7, False), (1, 100, 6, 7, True), (1, 3, 32, 7, True)])
+def test_conv_post_matches_oracle(lib, B, L, C, k, three):
+    rng = np.random.default_rng(L + C)
+    xs = [rng.standard_normal((B, C, L)).astype(np.float32) * 2 for _ in range(3 if three else 1)]
+    w = (rng.standard_normal((1, C, k)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(1).astype(np.float32)
+    x = xs[0]
+    if three:
+        x = ((xs[0] + xs[1]) + xs[2]) / np.float32(3)
+    want = np.tanh(orc.conv1d_np(orc.lrelu_np(x, 0.1), w, b, 1))[:, 0, :]
+    xd = [_cl(v) for v in xs]
+    yd = torch.full((B, L), float("nan"), device="cuda")
+    _check("op_conv_post", lib.iris_hifigan_op_conv_post(
+        xd[0].data_ptr(), xd[1].data_ptr() if three else None, xd[2].data_ptr() if three else None,
+        _fp(w), _fp(b), yd.data_ptr(), B, L, C, k, 0.1, None))
+    got = yd.cpu().numpy()
+    assert np.abs(got - want).max() <= 2e-6 + TOL_LAYER
+
+
+# ------------------------------------------------------------------------------------------------
+# whole generator
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["v1_default_T4_taps", "v1_default_B2_T16", "v1_amplified_T24", "small_cfg_B3_T19"])
+def test_generator_matches_reference_goldens(case, golden, case_setup, dev):
+    """HIP output vs the waveform the REFERENCE produced for the same weights and mel."""
+    from iris._engine import GeneratorEngine
+    cfg, sd = case_setup(case)
+    g = golden(case)
+    eng = GeneratorEngine(cfg, sd, dev)
+    got = eng.forward(torch.from_numpy(g["mel"]).to(dev)).cpu().numpy()
+    want = g["wav"][:, 0, :]
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= TOL_WAV
+    eng.close()
+
+
+@pytest.mark.parametrize("B,T,seed,log_mel", [(1, 100, 1001, False), (3, 57, 5, True), (1, 1, 9, False), (5, 2, 10, False)])
+def test_generator_matches_oracle(B, T, seed, log_mel, dev):
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    mel = seeded_mel(seed, B, T, log_mel=log_mel)
+    eng = GeneratorEngine(cfg, sd, dev)
+    got = eng.forward(torch.from_numpy(mel).to(dev)).cpu().numpy()
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel).numpy()[:, 0, :]
+    assert got.shape == (B, 256 * T)
+    assert np.abs(got - want).max() <= TOL_WAV
+    eng.close()
+
+
+def test_generator_empty_inputs(dev):
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_state_dict
+    cfg = GeneratorConfig()
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg), dev)
+    assert eng.forward(torch.empty((0, 80, 10), device=dev)).shape == (0, 2560)
+    assert eng.forward(torch.empty((2, 80, 0), device=dev)).shape == (2, 0)
+    with pytest.raises(ValueError):
+        eng.forward(torch.empty((2, 81, 4), device=dev))
+    eng.close()
+
+
+def test_generator_is_deterministic_and_batch_independent(dev):
+    """Batch items are independent: item b of a batch equals the same mel run alone."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0), dev)
+    mel = torch.from_numpy(seeded_mel(77, 4, 40)).to(dev)
+    full = eng.forward(mel).clone()
+    again = eng.forward(mel).clone()
+    assert torch.equal(full, again)
+    for b in range(4):
+        alone = eng.forward(mel[b:b + 1].contiguous())
+        assert torch.equal(alone[0], full[b])
+    eng.close()
+
+
+def test_profile_records_cover_algorithmic_work(dev):
+    from iris._engine import GeneratorEngine, algorithmic_work
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg), dev)
+    eng.set_profiling(True)
+    B, T = 2, 50
+    eng.forward(torch.from_numpy(seeded_mel(1, B, T)).to(dev))
+    torch.cuda.synchronize()
+    recs = eng.read_profile()
+    assert len(recs) == 31
+    work = algorithmic_work(cfg)
+    assert work["flop_per_frame"] == 614_105_088 and work["elements_per_frame"] == 1_305_936
+    assert sum(r["flops"] for r in recs) == pytest.approx(work["flop_per_frame"] * B * T, rel=1e-12)
+    act_bytes = sum(r["bytes"] for r in recs) - 4.0 * work["weight_values"]
+    assert act_bytes == pytest.approx(4.0 * work["elements_per_frame"] * B * T, rel=1e-12)
+    assert all(r["ms"] > 0 for r in recs)
+    eng.close()
