@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the HiFiGAN vocoder path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch B --frames T]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path -- mel [B, 80, T] -> waveform [B, 256*T] through
+``iris_hifigan_forward`` -- over one batch of synthetic mels that is already resident in HBM when
+the timed region starts.  N = 1 runs BASELINE.json configs[1] (batch 1, 80 x 1000 frames, fp32).
+For N > 1 every rank vocodes its own shard of the same size (weak scaling, no data-path collective
+but the final RCCL all-gather of the waveforms, which IS inside the step).
+
+The JSON line also carries
+  roofline      the dominant kernel (the MFMA Conv1d kernel behind the MRF ResBlocks): algorithmic
+                FLOP of its launches / their HIP-event durations, measured live in the timed region
+                on the stream the kernels run on; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+                The path is a dense contraction at 118 FLOP/B: fp32 is MFMA-bound, not HBM-bound
+                (SURVEY.md 8d), so ``bound`` is "mfma"; the HBM fraction of the same launches is
+                reported beside it as ``hbm_frac``.
+  cpu_baseline  the oracle (torch fp32 restatement of the reference, oracle/hifigan_oracle.py) timed on
+                this box's host cores on a bounded sample of the same workload; rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+for p in (str(REPO / "iris-tts_amd"), str(REPO)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SAMPLE_RATE = 22050
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0          # spec; 6.3 TB/s achievable
+
+
+def cpu_baseline(cfg, sd, mel, budget_s=20.0):
+    """Times the oracle's torch-fp32 forward (the arithmetic the reference's PyTorch twin runs) on the
+    host cores.  Bounded: 1 warm-up on a short clip, then whole utterances until ~budget_s is spent
+    (at least 1, at most 3)."""
+    import torch
+    from oracle import hifigan_oracle as orc
+
+    folded = orc.to_torch_folded(sd)
+    cores = torch.get_num_threads()
+    x = torch.from_numpy(mel)
+    orc.generator_forward_torch(folded, x[:, :, :50])            # warm-up (allocator, thread pool)
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        orc.generator_forward_torch(folded, x)
+        times.append(time.perf_counter() - t0)
+    best = statistics.median(times)
+    samples = mel.shape[0] * mel.shape[2] * 256
+    return {"value": samples / best, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full forward(s) of the same B={mel.shape[0]} x 80 x {mel.shape[2]} mel after one "
+                      f"50-frame warm-up; median {best:.3f} s; torch {torch.__version__} CPU fp32, "
+                      f"{cores} threads; oracle/hifigan_oracle.py:generator_forward_torch",
+            "rtf": best / (mel.shape[2] * 256 / SAMPLE_RATE) if mel.shape[0] == 1 else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="mels per GPU (default: configs[1], batch 1)")
+    ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from iris._engine import GeneratorEngine, algorithmic_work
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    from iris.distributed import gather_waveforms
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the vocoder path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2024)                       # random-init weights of the V1 architecture
+    B, T = args.batch, args.frames
+    mel_np = seeded_mel(1002 + rank, B, T)                       # SURVEY.md 8d seeds
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(mel_np).to(dev)
+    wav = torch.empty((B, T * eng.hop_length), dtype=torch.float32, device=dev)
+    gathered = torch.empty((B * world, T * eng.hop_length), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        eng.forward(mel, out=wav)
+        if world > 1:
+            gather_waveforms(wav, B * world, out=gathered)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    profile = not args.no_profile
+    fence()
+    eng.set_profiling(profile)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    recs = eng.read_profile() if profile else []
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = world * B * T * eng.hop_length
+    value = samples_per_step * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline of the dominant kernel, from the live HIP-event records -----------------------
+    roofline = None
+    detail = {}
+    if recs:
+        by_kind = {}
+        for r in recs:
+            k = by_kind.setdefault(r["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += 1
+        for kind, k in by_kind.items():
+            detail[kind] = {"launches_per_step": k["n"] // args.steps, "ms_per_step": k["ms"] / args.steps,
+                            "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12, "gbs": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
+        for stage in range(cfg.num_upsamples):
+            rs = [r for r in recs if r["kind"] == "mrf_resblock_conv" and r["stage"] == stage]
+            ms = sum(r["ms"] for r in rs)
+            detail[f"mrf_stage{stage}_C{cfg.stage_channels(stage)}"] = {
+                "ms_per_step": ms / args.steps, "tflops": sum(r["flops"] for r in rs) / (ms * 1e-3) / 1e12,
+                "gbs": sum(r["bytes"] for r in rs) / (ms * 1e-3) / 1e9}
+        dom = by_kind["mrf_resblock_conv"]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        roofline = {"kernel": "conv_mfma_f32_kernel (MRF ResBlock Conv1d groups, 24 launches/forward)",
+                    "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
+                    "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
+                    "bytes_per_launch": dom["bytes"] / dom["n"],
+                    "share_of_step": dom["ms"] / args.steps / ms_per_step}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    work = algorithmic_work(cfg)
+    out = {
+        "metric": "audio samples/sec (22.05 kHz) on 80-mel x %d-frame batch" % T,
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"HiFiGAN-V1 generator, batch {B} per GPU x 80-mel x {T} frames -> {T * eng.hop_length} samples "
+                               f"each, fp32" + (" (BASELINE.json configs[1])" if (B, T) == (1, 1000) else ""),
+                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "hop_length": eng.hop_length,
+                   "weights": "random-init (seeded) V1 architecture, 13,926,017 values",
+                   "sharding": "batch items across ranks, RCCL all-gather of waveforms" if world > 1 else "single GPU",
+                   "launch_events_in_timed_region": profile},
+        "rtf": (ms_per_step * 1e-3) / (T * eng.hop_length / SAMPLE_RATE) if B == 1 else None,
+        "flop_per_step": work["flop_per_frame"] * B * T * world,
+        "tflops_whole_path": work["flop_per_frame"] * B * T * world / (ms_per_step * 1e-3) / 1e12,
+        "roofline": roofline, "kernels": detail,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, mel_np)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,8 +116,9 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
 
 /* Profiling: when enabled every launch of forward is bracketed by hipEvents on `stream`.
- * After the stream has been synchronised, read_profile copies up to `capacity` records of the
- * LAST forward and returns how many launches it had. */
+ * Records accumulate over successive forwards until set_profiling is called again (which resets
+ * them).  After the stream has been synchronised, read_profile copies up to `capacity` records and
+ * returns how many launches were recorded. */
 int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled);
 int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_record* out,
                                   int32_t capacity, int32_t* n_launches);

@@ -4,7 +4,7 @@
 // Keras twin src/iris/vocoder.py:103-130):
 //   conv_pre -> for each stage { LeakyReLU -> ConvTranspose1d -> MRF(3 ResBlocks) / 3 } -> LeakyReLU
 //   -> conv_post -> tanh.
-// Launch plan for one forward (V1 config: 31 launches):
+// Launch plan for one forward (V1 config: 30 launches):
 //   1            conv_pre, reading the channels-first mel directly
 //   per stage:   1 upsample launch (all u phases as blockIdx.z; input = LeakyReLU of conv_pre, or
 //                LeakyReLU(mean of the previous stage's branch outputs) fused into the LDS staging)
@@ -353,7 +353,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
-    if (B == 0 || T == 0) { h->n_rec = 0; return IRIS_HIFIGAN_OK; }  // empty batch / empty mel -> empty waveform
+    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
     if (!mel_dev || !wav_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
     if (B > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "batch %d exceeds 65535 (grid.y)", B);
     if ((int64_t)T * h->hop > (int64_t)1 << 30)
@@ -367,7 +367,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     const float* blob = h->blob;
     const float slope = h->cfg.lrelu_slope;
     const int nk = h->cfg.num_kernels;
-    Prof prof{h, stream};
+    Prof prof{h, stream, h->profiling ? h->n_rec : 0};
     const double fB = (double)B;
 
     // ---- conv_pre (hifigan_pretrained.py:124) ----

@@ -107,9 +107,12 @@ class GeneratorEngine:
         _native.check("iris_hifigan_set_profiling", self.lib.iris_hifigan_set_profiling(self._handle, int(enabled)))
 
     def read_profile(self) -> List[dict]:
-        """Per-launch records of the last forward; the stream must have been synchronised."""
+        """Per-launch records of every forward since set_profiling(True); the stream must have
+        been synchronised."""
         n = ctypes.c_int32()
-        cap = 1024
+        _native.check("iris_hifigan_read_profile", self.lib.iris_hifigan_read_profile(
+            self._handle, None, 0, ctypes.byref(n)))
+        cap = max(int(n.value), 1)
         recs = (_native.LaunchRecord * cap)()
         _native.check("iris_hifigan_read_profile", self.lib.iris_hifigan_read_profile(
             self._handle, recs, cap, ctypes.byref(n)))

@@ -1,0 +1,227 @@
+"""CPU tests of the host side: weight-norm fold, blob order, checkpoint containers, wrapper
+semantics, C-ABI export table.  No GPU, no compute calls into the HIP library."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+from iris import _native
+from iris._weights import (GeneratorConfig, expected_weight_count, extract_state_dict, fold_weight_norm,
+                           folded_layers, keras_to_reference_layout, layer_specs, reference_to_keras_layout,
+                           seeded_mel, seeded_state_dict, state_dict_keys, weight_blob)
+
+
+def test_v1_layer_inventory_matches_reference(manifest):
+    cfg = GeneratorConfig()
+    specs = layer_specs(cfg)
+    assert len(specs) == 78                                   # 78 conv layers
+    assert sorted(state_dict_keys(cfg)) == manifest["state_dict_keys"]   # the reference's 234 keys
+    assert expected_weight_count(cfg) == 13_926_017            # effective weights + biases
+    assert cfg.hop_length == 256
+
+
+def test_fold_matches_reference_weight_norm(manifest, golden, case_setup):
+    """Effective weights as the reference's parametrised modules expose them (``module.weight``)."""
+    cfg, sd = case_setup("v1_default_T4_taps")
+    stats = manifest["folded_weight_stats"]
+    folded = {s.name: w for s, w, _ in folded_layers(cfg, sd)}
+    assert set(folded) == set(stats)
+    for name, (s1, s2) in stats.items():
+        w = folded[name].astype(np.float64)
+        assert w.sum() == pytest.approx(s1, rel=1e-5, abs=1e-5)
+        assert (w ** 2).sum() == pytest.approx(s2, rel=1e-5)
+    g = golden("v1_default_folded_weights")
+    for key, ref in g.items():
+        name = {"conv_post": "conv_post", "ups_3": "ups.3", "resblocks_9_convs1_0": "resblocks.9.convs1.0",
+                "resblocks_11_convs2_2": "resblocks.11.convs2.2"}[key]
+        assert np.abs(folded[name] - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
+
+
+def test_fold_norm_axis_for_transposed_conv():
+    """dim 0 is C_in for ConvTranspose1d: the norm runs over (C_out, k) per INPUT channel."""
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((6, 4, 5)).astype(np.float32)
+    g = rng.uniform(0.5, 2, (6, 1, 1)).astype(np.float32)
+    w = fold_weight_norm(g, v)
+    np.testing.assert_allclose(np.sqrt((w.astype(np.float64) ** 2).sum(axis=(1, 2))), g[:, 0, 0], rtol=1e-6)
+    t = torch._weight_norm(torch.from_numpy(v), torch.from_numpy(g), 0).numpy()
+    assert np.abs(w - t).max() <= 2e-7
+
+
+def test_blob_order_and_plain_weights_roundtrip():
+    cfg = GeneratorConfig(in_channels=8, upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4),
+                          upsample_initial_channel=16, resblock_kernel_sizes=(3, 5),
+                          resblock_dilation_sizes=((1, 2), (1, 3)))
+    sd = seeded_state_dict(cfg, seed=1)
+    blob = weight_blob(cfg, sd)
+    assert blob.dtype == np.float32 and blob.size == expected_weight_count(cfg)
+    # walk the blob in the documented order (include/iris_hifigan.h) and compare with the folds
+    off = 0
+    for spec, w, b in folded_layers(cfg, sd):
+        n = w.size
+        np.testing.assert_array_equal(blob[off:off + n].reshape(w.shape), w)
+        off += n
+        np.testing.assert_array_equal(blob[off:off + b.size], b)
+        off += b.size
+    assert off == blob.size
+    names = [s.name for s in layer_specs(cfg)]
+    assert names[:6] == ["conv_pre", "ups.0", "resblocks.0.convs1.0", "resblocks.0.convs1.1",
+                         "resblocks.0.convs2.0", "resblocks.0.convs2.1"]
+    # plain (already folded) weights are accepted too -- the Keras twin has no weight-norm
+    plain = {}
+    for spec, w, b in folded_layers(cfg, sd):
+        plain[f"{spec.name}.weight"], plain[f"{spec.name}.bias"] = w, b
+    np.testing.assert_array_equal(weight_blob(cfg, plain), blob)
+    with pytest.raises(KeyError):
+        weight_blob(cfg, {k: v for k, v in plain.items() if not k.startswith("ups.1")})
+    bad = dict(plain)
+    bad["conv_pre.weight"] = bad["conv_pre.weight"][:, :, :3]
+    with pytest.raises(ValueError):
+        weight_blob(cfg, bad)
+
+
+def test_keras_layout_map():
+    spec_c = [s for s in layer_specs(GeneratorConfig()) if s.name == "resblocks.0.convs1.1"][0]
+    spec_t = [s for s in layer_specs(GeneratorConfig()) if s.name == "ups.2"][0]
+    rng = np.random.default_rng(1)
+    kc = rng.standard_normal((3, 256, 256)).astype(np.float32)       # Conv1D [k, C_in, C_out]
+    kt = rng.standard_normal((4, 64, 128)).astype(np.float32)        # Conv1DTranspose [k, C_out, C_in]
+    wc, wt = keras_to_reference_layout(spec_c, kc), keras_to_reference_layout(spec_t, kt)
+    assert wc.shape == spec_c.weight_shape == (256, 256, 3) and wt.shape == spec_t.weight_shape == (128, 64, 4)
+    assert wc[5, 7, 2] == kc[2, 7, 5] and wt[100, 33, 1] == kt[1, 33, 100]
+    np.testing.assert_array_equal(reference_to_keras_layout(spec_c, wc), kc)
+
+
+def test_extract_state_dict_variants():
+    sd = {"a": 1}
+    for key in ("generator", "model", "state_dict"):
+        assert extract_state_dict({key: sd, "other": 0}) is sd
+    assert extract_state_dict(sd) is sd
+    # precedence as in the reference (hifigan_pretrained.py:174-182): generator > model > state_dict
+    assert extract_state_dict({"state_dict": 3, "model": 2, "generator": sd}) is sd
+    with pytest.raises(ValueError, match="Unexpected checkpoint format"):
+        extract_state_dict([1, 2])
+
+
+def test_seeded_generators_are_deterministic():
+    a, b = seeded_state_dict(seed=5), seeded_state_dict(seed=5)
+    assert all(np.array_equal(a[k], b[k]) for k in a) and len(a) == 234
+    assert not np.array_equal(a["conv_pre.weight_v"], seeded_state_dict(seed=6)["conv_pre.weight_v"])
+    m = seeded_mel(1002, 1, 1000)
+    assert m.shape == (1, 80, 1000) and m.dtype == np.float32
+    lm = seeded_mel(3, 2, 10, log_mel=True)
+    assert lm.min() >= np.float32(np.log(1e-5)) and lm.max() <= 2.0
+
+
+# ---- drop-in modules (no GPU: construction, state dict, errors) ------------------------------
+def test_hifigan_model_state_dict_is_reference_compatible(manifest):
+    from iris.hifigan_pretrained import HiFiGANModel
+    m = HiFiGANModel()
+    assert sorted(m.state_dict().keys()) == manifest["state_dict_keys"]
+    sd = seeded_state_dict(seed=2024)
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    np.testing.assert_array_equal(m.state_dict()["ups.1.weight_g"].numpy(), sd["ups.1.weight_g"])
+    assert m.ups[0].weight_v.shape == (512, 256, 16) and m.resblocks[11].convs2[2].weight_v.shape == (32, 32, 11)
+    small = HiFiGANModel(upsample_initial_channel=32)
+    assert small.conv_post.weight_v.shape == (1, 2, 7)
+    assert not m.training
+
+
+def test_generator_wrapper_errors_without_gpu(tmp_path, manifest):
+    from iris import hifigan_pretrained as hp
+    with pytest.raises(FileNotFoundError, match="Checkpoint not found"):
+        hp.HiFiGANGenerator(tmp_path / "missing.ckpt")
+    assert manifest["wrapper_semantics"]["missing_error"].startswith("FileNotFoundError: Checkpoint not found")
+    bad = tmp_path / "list.ckpt"
+    torch.save([1, 2, 3], bad)
+    with pytest.raises(ValueError, match="Unexpected checkpoint format"):
+        hp.HiFiGANGenerator(bad)
+    with pytest.raises(FileNotFoundError):
+        hp.get_pretrained_hifigan()          # the default path does not exist (no checkpoint ships)
+    assert "models--speechbrain--tts-hifigan-ljspeech" in str(hp.default_checkpoint_path())
+    if not torch.cuda.is_available():
+        ck = tmp_path / "generator.ckpt"
+        torch.save({"generator": {k: torch.from_numpy(v) for k, v in seeded_state_dict().items()}}, ck)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            hp.HiFiGANGenerator(ck)          # loud failure, never a CPU fallback
+
+
+def test_keras_twin_construction_and_weight_files(tmp_path):
+    from iris import vocoder
+    g = vocoder.HiFiGANGenerator(seed=0)
+    assert g.count_params() == 13_926_017
+    assert g.weights["conv_pre.kernel"].shape == (7, 80, 512)
+    assert g.weights["ups.0.kernel"].shape == (16, 256, 512)         # Conv1DTranspose [k, C_out, C_in]
+    assert not g.weights["conv_post.bias"].any()
+    lines = []
+    g.summary(print_fn=lines.append)
+    assert "13,926,017" in lines[-1]
+    path = tmp_path / "w.npz"
+    g.save_weights(str(path))
+    g2 = vocoder.HiFiGANGenerator(seed=1)
+    g2.load_weights(str(path))
+    np.testing.assert_array_equal(g2.weights["ups.2.kernel"], g.weights["ups.2.kernel"])
+    sd = g.reference_state_dict()
+    assert sd["ups.0.weight"].shape == (512, 256, 16) and sd["conv_pre.weight"].shape == (512, 80, 7)
+    with pytest.raises(NotImplementedError):
+        g.load_weights(str(tmp_path / "w.weights.h5"))
+    if not torch.cuda.is_available():
+        voc = vocoder.create_vocoder(str(tmp_path / "does_not_exist.keras"))   # no error, random weights
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            voc.infer(np.zeros((80, 4)))
+
+
+# ---- C-ABI ------------------------------------------------------------------------------------
+def test_cabi_exports_every_declared_symbol():
+    header = (REPO / "include" / "iris_hifigan.h").read_text()
+    declared = set(re.findall(r"\b(iris_hifigan_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.iris_hifigan_abi_version() == 1
+    assert ctypes.sizeof(_native.Config) == 4 * (3 + 8 + 8 + 1 + 8 + 8 + 64 + 2) + 4
+    assert ctypes.sizeof(_native.LaunchRecord) == 40
+
+
+def test_cabi_argument_validation_without_gpu():
+    """Pure host-side checks of the library (no kernel launch, no device needed)."""
+    lib = _native.load()
+    cfg = GeneratorConfig()
+    n = ctypes.c_uint64()
+    assert lib.iris_hifigan_weight_count(ctypes.byref(_native.make_config(cfg)), ctypes.byref(n)) == 0
+    assert n.value == expected_weight_count(cfg)
+    small = GeneratorConfig(in_channels=20, upsample_rates=(4, 2, 3), upsample_kernel_sizes=(8, 4, 9),
+                            upsample_initial_channel=48, resblock_kernel_sizes=(3, 5),
+                            resblock_dilation_sizes=((1, 2), (2, 6)))
+    assert lib.iris_hifigan_weight_count(ctypes.byref(_native.make_config(small)), ctypes.byref(n)) == 0
+    assert n.value == expected_weight_count(small)
+    bad = _native.make_config(cfg)
+    bad.upsample_kernel_sizes[0] = 15            # (k - u) odd: the reference's padding (k-u)//2 would change L_out
+    assert lib.iris_hifigan_weight_count(ctypes.byref(bad), ctypes.byref(n)) == 1
+    assert b"kernel" in lib.iris_hifigan_last_error()
+    bad = _native.make_config(cfg)
+    bad.num_upsamples = 9
+    assert lib.iris_hifigan_weight_count(ctypes.byref(bad), ctypes.byref(n)) == 1
+    with pytest.raises(_native.NativeCallError):
+        _native.check("iris_hifigan_forward", lib.iris_hifigan_forward(None, None, 1, 1, None, None, 0, 0, None))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setenv("IRIS_HIFIGAN_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_product_never_imports_the_oracle():
+    for path in (REPO / "iris-tts_amd").rglob("*"):
+        if path.suffix in (".py", ".hip", ".h", ".cpp") and path.is_file():
+            text = path.read_text()
+            assert "import oracle" not in text and "from oracle" not in text and "hifigan_oracle" not in text, path
