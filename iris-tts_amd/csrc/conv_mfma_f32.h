@@ -26,11 +26,12 @@
 //   B fragment (ci x co):   one 16-byte global load per 4 MFMAs from weights repacked on the host
 //                           into fragment order (pack_conv1d_weights), served by L2.
 //   Accumulators:           MT tiles of 32x32 (16 VGPRs each).
-// blockIdx.z selects one of up to 8 independent problems of identical shape (the MRF branches of
+// blockIdx.x % nz selects one of up to 8 independent problems of identical shape (the MRF branches of
 // one stage, kernel sizes 3/7/11: three ResBlocks advance in one launch) or the ConvTranspose phase.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace iris {
 
@@ -66,6 +67,11 @@ struct ConvLaunch {
     int in_act;
     int x_channels_first;
     float slope;
+    int ablate;          // diagnostics only (env IRIS_HIFIGAN_ABLATE): 1 skip staging, 2 weights from one
+                         // address, 4 skip epilogue stores, 8 skip residual read.  Results are wrong.
+    int z_serial;        // 1: every block loops over all nz_serial problems of its tile (equal-cost blocks)
+    int nz_serial;
+    int nz;              // problems (or phases) interleaved along blockIdx.x
     int n_co_blk;        // blocks along C_out
     int Gp;              // padded number of 8-channel groups in the packed weights
     int n_ct;            // number of 32-wide C_out tiles in the packed weights
@@ -145,7 +151,8 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
     const int ks = KS > 0 ? KS : p.ks;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = wave / WC, wc = wave - wt * WC;
-    const int tile_co = blockIdx.x % a.n_co_blk, tile_t = blockIdx.x / a.n_co_blk;
+    const int bid = blockIdx.x / a.nz;          // blockIdx.x = (tile index) * nz + z
+    const int tile_co = bid % a.n_co_blk, tile_t = bid / a.n_co_blk;
     const int b = blockIdx.y;
     const int i0 = tile_t * T_BLK;
     const int R = T_BLK + (ks - 1) * p.dil;
@@ -162,36 +169,65 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
 
     const float* aptr = lds + (wt * MT * 32 + lo) * S + 4 * hi;
     const f32x4* wlane = wp + (size_t)ct * 64 + lane;
-    const size_t wstep = (size_t)a.n_ct * 64;  // f32x4 elements per (tap, group)
+    const size_t wstep = (a.ablate & 2) ? 0 : (size_t)a.n_ct * 64;  // f32x4 elements per (tap, group)
 
     for (int c0 = 0; c0 < a.C_in; c0 += CIC) {
         if (c0 > 0) __syncthreads();
-        stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
+        if (!(a.ablate & 1)) stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
         __syncthreads();
         if (wave_active) {
             const int g0 = c0 >> 3;
-            auto tap = [&](int kk) {
-                const float* ak = aptr + kk * p.dil * S;
-                const f32x4* wk = wlane + ((size_t)kk * a.Gp + g0) * wstep;
+            // One "group" = 8 input channels of one tap = 4*MT MFMAs.  Fragments of group n+1
+            // (LDS) and n+2 (weights, L2) are requested before the MFMAs of group n issue.
+            constexpr int GPC = CIC / 8;                       // groups per tap in this chunk
+            const int n_groups = ks * GPC;
+            auto a_ptr = [&](int n) { const int kk = n / GPC, g = n - kk * GPC;
+                                      return aptr + kk * p.dil * S + 8 * g; };
+            auto b_ptr = [&](int n) { const int kk = n / GPC, g = n - kk * GPC;
+                                      return wlane + ((size_t)kk * a.Gp + g0 + g) * wstep; };
+            auto mfma_group = [&](const f32x4 (&av)[MT], const f32x4& bw) {
 #pragma unroll
-                for (int g = 0; g < CIC / 8; ++g) {
-                    const f32x4 bw = wk[(size_t)g * wstep];
-                    f32x4 av[MT];
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        av[m] = *reinterpret_cast<const f32x4*>(ak + m * 32 * S + 8 * g);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bw[e], acc[m], 0, 0, 0);
+            };
+            auto load_a = [&](f32x4 (&av)[MT], int n) {
+                const float* ap = a_ptr(n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bw[e], acc[m], 0, 0, 0);
-                }
+                for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(ap + m * 32 * S);
             };
             if constexpr (KS > 0) {
+                constexpr int NG = KS * GPC;
+                f32x4 av0[MT], av1[MT], bw0, bw1, bw2;
+                load_a(av0, 0);
+                bw0 = *b_ptr(0);
+                bw1 = *b_ptr(NG > 1 ? 1 : 0);
+                // sched_barrier(0): hipcc otherwise sinks every load back next to its first use
+                // (global_load followed by vmcnt(0)), exposing the L2 latency once per group.
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) tap(kk);
+                for (int n = 0; n < NG; n += 2) {
+                    if (n + 1 < NG) load_a(av1, n + 1);
+                    if (n + 2 < NG) bw2 = *b_ptr(n + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_group(av0, bw0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (n + 1 < NG) {
+                        if (n + 2 < NG) load_a(av0, n + 2);
+                        if (n + 3 < NG) bw0 = *b_ptr(n + 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_group(av1, bw1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        bw1 = bw0; bw0 = bw2;                  // rotate: bw0 <- group n+2, bw1 <- group n+3
+                    }
+                }
             } else {
-                for (int kk = 0; kk < ks; ++kk) tap(kk);
+                for (int n = 0; n < n_groups; ++n) {
+                    f32x4 av[MT];
+                    load_a(av, n);
+                    const f32x4 bw = *b_ptr(n);
+                    mfma_group(av, bw);
+                }
             }
         }
     }
@@ -210,20 +246,16 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
             if (i < a.n_idx && o >= 0 && o < a.L_out) {
                 const size_t off = ((size_t)b * a.L_out + o) * a.C_out + co;
                 float v = acc[m][r] + bias;
-                if (p.res) v += p.res[off];
-                p.y[off] = v;
+                if (p.res && !(a.ablate & 8)) v += p.res[off];
+                if (!(a.ablate & 4) || v == 1.2345e-30f) p.y[off] = v;
             }
         }
     }
 }
 
 template <int WT, int WC, int MT, int CIC>
-__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvLaunch a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int z = blockIdx.z;
-    const ConvProblem& p = a.p[a.z_is_phase ? 0 : z];
-    const f32x4* wp = p.wp + (a.z_is_phase ? (int64_t)z * a.phase_wp_stride : 0);
-    const int out_off = a.out_off + (a.z_is_phase ? z : 0);
+__device__ __forceinline__ void conv_dispatch(const ConvLaunch& a, const ConvProblem& p, const f32x4* wp,
+                                              int out_off, float* lds) {
     switch (p.ks) {
         case 2:  conv_body<2,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
         case 3:  conv_body<3,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
@@ -231,6 +263,35 @@ __global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvLaunch a) 
         case 11: conv_body<11, WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
         default: conv_body<0,  WT, WC, MT, CIC>(a, p, wp, out_off, lds); break;
     }
+}
+
+template <int WT, int WC, int MT, int CIC>
+__global__ void __launch_bounds__(256) conv_mfma_f32_kernel(const ConvLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (a.z_serial) {
+        // Equal-cost blocks: one block runs ALL problems (MRF branches, k = 3/7/11) of its tile one
+        // after the other, so every block of the launch costs the same whatever mix of kernel
+        // sizes the stage has.
+        // The starting branch rotates with the block index (a.z_serial == 2): blocks that share a CU
+        // are then in different phases (staging / MFMA / epilogue) instead of marching in lock-step.
+        const int rot = a.z_serial == 2 ? (int)(blockIdx.x % a.nz_serial) : 0;
+        for (int zi = 0; zi < a.nz_serial; ++zi) {
+            int z = a.nz_serial - 1 - zi + rot;
+            if (z >= a.nz_serial) z -= a.nz_serial;
+            conv_dispatch<WT, WC, MT, CIC>(a, a.p[z], a.p[z].wp, a.out_off, lds);
+            if (zi + 1 < a.nz_serial) __syncthreads();
+        }
+        return;
+    }
+    // z = MRF branch (or ConvTranspose phase) is the fastest-varying part of blockIdx.x, so blocks
+    // that are dispatched together -- and share a CU -- mix the cheap (k=3) and the expensive (k=11)
+    // branches; branches are taken heaviest-first (the packed order is k ascending).
+    const int zr = blockIdx.x % a.nz;
+    const int z = a.z_is_phase ? zr : a.nz - 1 - zr;
+    const ConvProblem& p = a.p[a.z_is_phase ? 0 : z];
+    const f32x4* wp = p.wp + (a.z_is_phase ? (int64_t)z * a.phase_wp_stride : 0);
+    const int out_off = a.out_off + (a.z_is_phase ? z : 0);
+    conv_dispatch<WT, WC, MT, CIC>(a, p, wp, out_off, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -320,7 +381,14 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     }
     const size_t lds_bytes = (size_t)(t.T_BLK + span) * (t.CIC + 4) * sizeof(float);
     const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
-    dim3 grid((unsigned)(n_t * a.n_co_blk), (unsigned)a.B, (unsigned)nz), block(256);
+    static const int serial_env = [] { const char* e = getenv("IRIS_HIFIGAN_ZSERIAL"); return e ? atoi(e) : 1; }();
+    a.z_serial = (!a.z_is_phase && nz > 1 && serial_env) ? serial_env : 0;
+    a.nz_serial = nz;
+    if (a.z_serial) nz = 1;
+    a.nz = nz;
+    static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate_env;
+    dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
 #define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
     do {                                                                                          \

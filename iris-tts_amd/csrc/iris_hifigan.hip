@@ -19,10 +19,12 @@
 #include <stdarg.h>
 #include <string.h>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/iris_hifigan.h"
 #include "conv_mfma_f32.h"
+#include "mrf_conv_mfma_f32.h"
 #include "conv_post.h"
 
 using namespace iris;
@@ -75,8 +77,10 @@ struct iris_hifigan_handle {
     int device = 0;
     // profiling
     bool profiling = false;
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev;          // event pool, n_ev in use
+    size_t n_ev = 0;
     std::vector<iris_hifigan_launch_record> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec_ev;  // (start, end) event of each record
     int n_rec = 0;
 };
 
@@ -212,27 +216,43 @@ WsLayout ws_layout(const iris_hifigan_handle* h, int B, int T) {
     return w;
 }
 
+// Launch timing with ONE event per launch boundary: event e_k sits between launch k-1 and launch k
+// of a forward, so launch k lasted elapsed(e_k, e_{k+1}) (its start-up gap included).  A forward of
+// n launches records n + 1 events.
 struct Prof {
     iris_hifigan_handle* h;
     hipStream_t stream;
-    int idx = 0;
-    int begin(int kind, int stage, int step, double flops, double bytes) {
-        if (!h->profiling) return IRIS_HIFIGAN_OK;
-        if ((size_t)(2 * idx + 2) > h->ev.size()) {
+    int idx = 0;        // next record
+    bool open = false;  // a start event for the next launch is already on the stream
+    int mark(hipEvent_t* out) {
+        if (h->n_ev >= h->ev.size()) {
             const size_t old = h->ev.size();
-            h->ev.resize(2 * idx + 2);
+            h->ev.resize(old + 64);
             for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
         }
-        if ((size_t)idx >= h->recs.size()) h->recs.resize(idx + 1);
+        *out = h->ev[h->n_ev++];
+        HIP_TRY(hipEventRecord(*out, stream));
+        return IRIS_HIFIGAN_OK;
+    }
+    int begin(int kind, int stage, int step, double flops, double bytes) {
+        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        if ((size_t)idx >= h->recs.size()) { h->recs.resize(idx + 64); h->rec_ev.resize(idx + 64); }
         iris_hifigan_launch_record& r = h->recs[idx];
         memset(&r, 0, sizeof(r));
         r.kind = kind; r.stage = stage; r.step = step; r.flops = flops; r.bytes = bytes;
-        HIP_TRY(hipEventRecord(h->ev[2 * idx], stream));
+        if (!open) {
+            int rc = mark(&h->rec_ev[idx].first);
+            if (rc != IRIS_HIFIGAN_OK) return rc;
+        } else {
+            h->rec_ev[idx].first = h->rec_ev[idx - 1].second;
+        }
         return IRIS_HIFIGAN_OK;
     }
     int end() {
         if (!h->profiling) return IRIS_HIFIGAN_OK;
-        HIP_TRY(hipEventRecord(h->ev[2 * idx + 1], stream));
+        int rc = mark(&h->rec_ev[idx].second);
+        if (rc != IRIS_HIFIGAN_OK) return rc;
+        open = true;
         ++idx;
         return IRIS_HIFIGAN_OK;
     }
@@ -331,6 +351,7 @@ int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     h->profiling = enabled != 0;
     h->n_rec = 0;
+    h->n_ev = 0;
     return IRIS_HIFIGAN_OK;
 }
 
@@ -340,7 +361,7 @@ int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_re
     *n_launches = h->n_rec;
     for (int i = 0; i < h->n_rec; ++i) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, h->rec_ev[i].first, h->rec_ev[i].second));
         h->recs[i].ms = ms;
         if (out && i < capacity) out[i] = h->recs[i];
     }
@@ -437,7 +458,9 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops,
                                4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
-                HIP_TRY(launch_conv(a, nk, stream));
+                static const int use_mrf = [] { const char* e = getenv("IRIS_HIFIGAN_MRF"); return e ? atoi(e) : 1; }();
+                if (use_mrf && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
+                else                                         HIP_TRY(launch_conv(a, nk, stream));
                 TRY(prof.end());
             }
         }

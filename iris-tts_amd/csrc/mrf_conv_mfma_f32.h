@@ -1,0 +1,270 @@
+// mrf_conv_mfma_f32.h -- the hot kernel: one conv step of ALL MRF ResBlock branches of a stage.
+//
+// Reference semantics: ResBlock.forward, src/iris/hifigan_pretrained.py:64-71, for the three
+// branches of a stage (kernel sizes 3/7/11, hifigan_pretrained.py:130-136):
+//     step 2m   : xt_j = Conv1d_dil(LeakyReLU(x_j))            (convs1[m], dilation 1/3/5)
+//     step 2m+1 : x_j  = Conv1d(LeakyReLU(xt_j)) + x_j          (convs2[m] + residual)
+//
+// Same MFMA formulation, LDS image and packed weights as conv_mfma_f32.h; what differs is the
+// schedule, which is what the first profile asked for (profiles/r01*: MFMA pipe 45-74 % busy, and an
+// ablation with every memory access removed still at 108-131 TFLOP/s):
+//   * equal-cost blocks: a block owns one (time tile, C_out block) and runs the branches
+//     k = 11, 7, 3 back to back ("phases" = branch x C_in chunk), so block cost no longer depends
+//     on the kernel size and blocks live ~70 us instead of ~3-20 us;
+//   * the global loads that stage phase p+1's input window are issued DURING the MFMAs of phase p,
+//     one 16-byte load per MFMA group, and written to LDS after the phase (register staging,
+//     "issue early / write late"); one LDS buffer, two barriers per phase;
+//   * weight fragments are requested DB groups (DB * 4*MT MFMAs) ahead.  vmcnt retires in order, so a
+//     wait for weight fragment n also waits for every older staging load: spreading the staging loads
+//     one per group gives each of them DB groups (~DB*512 cycles) of flight time before any wave
+//     can stall on it.
+#pragma once
+#include <type_traits>
+#include "conv_mfma_f32.h"
+
+namespace iris {
+
+constexpr int kMrfSpanMax = 50;  // (ks-1)*dil of the widest supported conv: k=11, d=5
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer loads (T8/T20 of the CDNA guide): the 128-bit descriptor is built from kernel arguments
+// and blockIdx only (provably wave-uniform -> SGPRs, no waterfall loop); every load then needs ONE
+// 32-bit VGPR offset instead of a live 64-bit per-lane address, and the hardware range check
+// (offset >= num_records -> 0) implements the zero padding of the convolution for free.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
+}
+constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
+
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC>
+__global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = CIC + 4;
+    constexpr int QPR = CIC / 4;
+    constexpr int GPC = CIC / 8;
+    constexpr int T_BLK = WT * MT * 32;
+    constexpr int NQ = ((T_BLK + kMrfSpanMax) * QPR + 255) / 256;  // staged 16-byte quads per thread
+    constexpr int RPI = 256 / QPR;                                   // rows advanced per staged quad
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave / WC, wc = wave - wt * WC;
+    const int tile_co = blockIdx.x % a.n_co_blk, tile_t = blockIdx.x / a.n_co_blk;
+    const int b = blockIdx.y;
+    const int i0 = tile_t * T_BLK;
+    const int ct_raw = tile_co * WC + wc;
+    const bool wave_active = ct_raw < a.n_ct;                 // wave-uniform
+    const int ct = wave_active ? ct_raw : a.n_ct - 1;         // inactive waves compute a duplicate, store nothing
+    const int lo = lane & 31, hi = lane >> 5;
+    const int L = a.L_in, C = a.C_in;
+    const int n_chunks = (C + CIC - 1) / CIC;
+    const size_t batch_off = (size_t)b * L * C;
+    const unsigned wbytes_group = (a.ablate & 2) ? 0u : (unsigned)a.n_ct * 64u * 16u;  // bytes per (tap, group)
+    const unsigned tap_bytes = (unsigned)a.Gp * wbytes_group;
+    const unsigned wvoff = (unsigned)(ct * 64 + lane) * 16u;
+    const float* aptr = lds + (wt * MT * 32 + lo) * S + 4 * hi;
+    const int co_lane = ct * 32 + lo;
+    // byte offset of this lane's first output element (row i0 + wave rows + 4*hi, channel co)
+    const unsigned ovoff = (wave_active && co_lane < a.C_out)
+                               ? (unsigned)((i0 + wt * MT * 32 + 4 * hi) * C + co_lane) * 4u : kOobOffset;
+    const float slope = a.slope;
+    const int ablate = a.ablate;
+
+    // One staged quad = 16 bytes of row (in_row0 + r_lane + i*RPI), channels [c0+4q, c0+4q+4).
+    // Its byte offset inside this batch item's [L, C] tensor is vbase + i*row_stride; rows < 0 wrap
+    // to >= 2^31 and rows >= L exceed num_records: both read 0.
+    const int r_lane = tid / QPR, q_lane = tid - r_lane * QPR;
+    const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
+    const unsigned row_stride = (unsigned)(RPI * C) * 4u;
+    float* const lds_wr = lds + r_lane * S + 4 * q_lane;     // + i * RPI * S for quad i
+    f32x4 st[NQ];
+    auto stage_vbase = [&](int in_row0, int c0) -> unsigned {
+        const int ci = c0 + 4 * q_lane;
+        if (ci >= C || (ablate & 1)) return kOobOffset;
+        return (unsigned)((in_row0 + r_lane) * C + ci) * 4u;
+    };
+    auto stage_load_one = [&](int i, __amdgpu_buffer_rsrc_t xr, unsigned vbase) {
+        st[i] = buf_load4(xr, vbase + (unsigned)i * row_stride, 0);
+    };
+    auto stage_write_all = [&](int R) {      // LeakyReLU on the way in (hifigan_pretrained.py:66,68)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            if (r_lane + i * RPI < R) *reinterpret_cast<f32x4*>(lds_wr + i * RPI * S) = lrelu4(st[i], slope);
+    };
+
+    f32x16 acc[MT];
+
+    // One branch (problem p, KS taps): all C_in chunks, then its epilogue.  `pn` = the branch that
+    // follows (its first window is prefetched during this branch's last chunk), or nullptr.
+    auto run_branch = [&](auto ks_tag, const ConvProblem& p, const ConvProblem* pn) {
+        constexpr int KS = decltype(ks_tag)::value;
+        constexpr int NG = KS * GPC;
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, (unsigned)(KS * a.Gp) * wbytes_group);
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + batch_off, tensor_bytes);
+        const int dilS = p.dil * S;
+        // Output / residual element (m, r) of this lane sits at ovoff + (m*32 + (r&3) + 8*(r>>2)) rows:
+        // the row part goes into the scalar offset, rows >= L fall outside num_records (store dropped,
+        // load 0), lanes with co >= C_out get an out-of-range ovoff.  A branch without residual uses a
+        // zero-length descriptor, whose loads return 0.
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + batch_off, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + batch_off : p.y, (p.res && !(ablate & 8)) ? tensor_bytes : 0u);
+        constexpr int RPG = (MT * 16 + NG - 1) / NG;     // residual loads issued per MFMA group
+        float resv[MT * 16];
+        auto res_load = [&](int idx) {
+            const int m = idx / 16, r = idx % 16;
+            resv[idx] = buf_load1(rr, ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+        };
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+        for (int chunk = 0; chunk < n_chunks; ++chunk) {
+            const bool last = chunk + 1 == n_chunks;
+            const bool has_next = !last || pn != nullptr;
+            // the window staged during this chunk: next chunk of this branch, or chunk 0 of the next one
+            const ConvProblem& q = last && pn ? *pn : p;
+            const __amdgpu_buffer_rsrc_t xrn = last && pn ? make_rsrc(q.x + batch_off, tensor_bytes) : xr;
+            const int Rn = T_BLK + (q.ks - 1) * q.dil;
+            const unsigned vbn = stage_vbase(i0 - q.pad_left, last ? 0 : (chunk + 1) * CIC);
+            const unsigned wsoff0 = (unsigned)(chunk * GPC) * wbytes_group;
+
+            auto a_ptr = [&](int n) { return aptr + (n / GPC) * dilS + 8 * (n % GPC); };
+            auto b_load = [&](int n) {
+                return buf_load4(wr, wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
+            };
+            f32x4 bw[DB + 1];
+            f32x4 av[2][MT];
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+                if (d < NG) bw[d] = b_load(d);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(a_ptr(0) + m * 32 * S);
+#pragma unroll
+            for (int n = 0; n < NG; ++n) {
+                if (n < NQ && has_next) stage_load_one(n, xrn, vbn);
+                if (last) {
+#pragma unroll
+                    for (int j = 0; j < RPG; ++j)
+                        if (n * RPG + j < MT * 16) res_load(n * RPG + j);
+                }
+                if (n + DB < NG) bw[(n + DB) % (DB + 1)] = b_load(n + DB);
+                if (n + 1 < NG) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        av[(n + 1) & 1][m] = *reinterpret_cast<const f32x4*>(a_ptr(n + 1) + m * 32 * S);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n & 1][m][e], bw[n % (DB + 1)][e], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (has_next) {
+#pragma unroll
+                for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn);
+            }
+
+            if (last) {
+                // epilogue of this branch. D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                const float bias = p.bias[co_lane < a.C_out ? co_lane : 0];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[m][r] + bias + resv[m * 16 + r];
+                        if (!(ablate & 4) || v == 1.2345e-30f)
+                            buf_store1(v, yr, ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+                    }
+                }
+            }
+            if (has_next) {
+                __syncthreads();          // every wave is done reading this chunk's window
+                stage_write_all(Rn);
+                __syncthreads();
+            }
+        }
+    };
+
+    {   // prologue: the first window (the only staging latency a block ever exposes)
+        const ConvProblem& p0 = a.p[2];
+        const int R0 = T_BLK + (p0.ks - 1) * p0.dil;
+        const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p0.x + batch_off, tensor_bytes);
+        const unsigned vb0 = stage_vbase(i0 - p0.pad_left, 0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) stage_load_one(i, xr0, vb0);
+        stage_write_all(R0);
+        __syncthreads();
+    }
+    // branches heaviest first: p[2] (KC taps), p[1] (KB), p[0] (KA)
+    run_branch(std::integral_constant<int, KC>{}, a.p[2], &a.p[1]);
+    run_branch(std::integral_constant<int, KB>{}, a.p[1], &a.p[0]);
+    run_branch(std::integral_constant<int, KA>{}, a.p[0], nullptr);
+}
+
+// True when the grouped launch `a` (nz problems) can take the MRF kernel.
+inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
+    if (a.z_is_phase || a.x_channels_first || a.in_act == IN_ACT_MRF_LRELU) return false;
+    if (a.C_in != a.C_out || (a.C_in & 3) || a.L_in != a.L_out || a.out_stride != 1 || a.out_off != 0) return false;
+    if (a.n_idx != a.L_out) return false;
+    if ((uint64_t)a.L_in * a.C_in * 4u >= 0x7fffffffull) return false;       // 32-bit buffer offsets
+    if (nz != 3 || a.p[0].ks != 3 || a.p[1].ks != 7 || a.p[2].ks != 11) return false;   // the V1 MRF
+    if (a.in_act != IN_ACT_LRELU) return false;
+    for (int j = 0; j < nz; ++j) {
+        if (packed_conv1d_floats(a.C_in, a.C_out, a.p[j].ks) * 4u >= 0x7fffffffull) return false;
+        const int ks = a.p[j].ks;
+        if (ks != 3 && ks != 7 && ks != 11) return false;
+        if ((ks - 1) * a.p[j].dil > kMrfSpanMax) return false;
+    }
+    return true;
+}
+
+inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
+    const ConvTile t = pick_tile(a.C_in, a.C_out);
+    a.n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
+    a.Gp = packed_groups(a.C_in);
+    a.n_ct = packed_cotiles(a.C_out);
+    a.z_serial = 1;
+    a.nz_serial = nz;
+    a.nz = 1;
+    static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int db_env = [] { const char* e = getenv("IRIS_HIFIGAN_DB"); return e ? atoi(e) : 4; }();
+    a.ablate = ablate_env;
+    const size_t lds_bytes = (size_t)(t.T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
+    const int n_t = (a.L_out + t.T_BLK - 1) / t.T_BLK;
+    dim3 grid((unsigned)(n_t * a.n_co_blk), (unsigned)a.B, 1u), block(256);
+#define IRIS_MRF_LAUNCH(WT_, WC_, CIC_, DB_)                                                     \
+    do {                                                                                          \
+        auto kfn = mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, DB_, 3, 7, 11>;                              \
+        if (lds_bytes > 64 * 1024) {                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               (int)lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+    } while (0)
+#define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
+    do { if (db_env >= 6) IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 6); else IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 4); } while (0)
+    if (t.WT == 4 && t.CIC == 32)      IRIS_MRF_LAUNCH_DB(4, 1, 32);
+    else if (t.WT == 4)                IRIS_MRF_LAUNCH_DB(4, 1, 64);
+    else if (t.WT == 2)                IRIS_MRF_LAUNCH_DB(2, 2, 64);
+    else                               IRIS_MRF_LAUNCH_DB(1, 4, 64);
+#undef IRIS_MRF_LAUNCH_DB
+#undef IRIS_MRF_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace iris
