@@ -59,32 +59,47 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave / WC, wc = wave - wt * WC;
-    const int tile_co = blockIdx.x % a.n_co_blk, tile_t = blockIdx.x / a.n_co_blk;
-    const int b = blockIdx.y;
-    const int i0 = tile_t * T_BLK;
-    const int ct_raw = tile_co * WC + wc;
-    const bool wave_active = ct_raw < a.n_ct;                 // wave-uniform
-    const int ct = wave_active ? ct_raw : a.n_ct - 1;         // inactive waves compute a duplicate, store nothing
     const int lo = lane & 31, hi = lane >> 5;
     const int L = a.L_in, C = a.C_in;
     const int n_chunks = (C + CIC - 1) / CIC;
-    const size_t batch_off = (size_t)b * L * C;
+    const int n_t = (L + T_BLK - 1) / T_BLK;
+    const int tiles_per_item = n_t * a.n_co_blk;
+    const int n_tiles = tiles_per_item * a.B;
     const unsigned wbytes_group = (a.ablate & 2) ? 0u : (unsigned)a.n_ct * 64u * 16u;  // bytes per (tap, group)
     const unsigned tap_bytes = (unsigned)a.Gp * wbytes_group;
-    const unsigned wvoff = (unsigned)(ct * 64 + lane) * 16u;
     const float* aptr = lds + (wt * MT * 32 + lo) * S + 4 * hi;
-    const int co_lane = ct * 32 + lo;
-    // byte offset of this lane's first output element (row i0 + wave rows + 4*hi, channel co)
-    const unsigned ovoff = (wave_active && co_lane < a.C_out)
-                               ? (unsigned)((i0 + wt * MT * 32 + 4 * hi) * C + co_lane) * 4u : kOobOffset;
     const float slope = a.slope;
     const int ablate = a.ablate;
+    const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
+
+    // A tile = (batch item, time tile, C_out block).  Everything a phase needs to know about it:
+    struct Tile {
+        size_t batch_off;   // elements to this batch item's [L, C] tensor
+        int i0;             // first output row
+        unsigned wvoff;     // this lane's byte offset inside a (tap, group) of packed weights
+        unsigned ovoff;     // this lane's byte offset of output element (m=0, r=0), or out of range
+        int co_lane;
+    };
+    auto make_tile = [&](int tile) {
+        Tile t;
+        const int b = tile / tiles_per_item, rem = tile - b * tiles_per_item;
+        const int tile_co = rem % a.n_co_blk, tile_t = rem / a.n_co_blk;
+        const int ct_raw = tile_co * WC + wc;
+        const bool active = ct_raw < a.n_ct;                   // wave-uniform
+        const int ct = active ? ct_raw : a.n_ct - 1;           // idle waves compute a duplicate, store nothing
+        t.batch_off = (size_t)b * L * C;
+        t.i0 = tile_t * T_BLK;
+        t.wvoff = (unsigned)(ct * 64 + lane) * 16u;
+        t.co_lane = ct * 32 + lo;
+        t.ovoff = (active && t.co_lane < a.C_out)
+                      ? (unsigned)((t.i0 + wt * MT * 32 + 4 * hi) * C + t.co_lane) * 4u : kOobOffset;
+        return t;
+    };
 
     // One staged quad = 16 bytes of row (in_row0 + r_lane + i*RPI), channels [c0+4q, c0+4q+4).
-    // Its byte offset inside this batch item's [L, C] tensor is vbase + i*row_stride; rows < 0 wrap
-    // to >= 2^31 and rows >= L exceed num_records: both read 0.
+    // Its byte offset inside the batch item's tensor is vbase + i*row_stride; rows < 0 wrap to
+    // >= 2^31 and rows >= L exceed num_records: both read 0.
     const int r_lane = tid / QPR, q_lane = tid - r_lane * QPR;
-    const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
     const unsigned row_stride = (unsigned)(RPI * C) * 4u;
     float* const lds_wr = lds + r_lane * S + 4 * q_lane;     // + i * RPI * S for quad i
     f32x4 st[NQ];
@@ -103,26 +118,31 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
     };
 
     f32x16 acc[MT];
+    f32x4 bw[DB + 1];     // ring of weight fragments; groups 0..DB-1 of a phase are requested by the
+                          // phase before it (or by the prologue)
 
-    // One branch (problem p, KS taps): all C_in chunks, then its epilogue.  `pn` = the branch that
-    // follows (its first window is prefetched during this branch's last chunk), or nullptr.
-    auto run_branch = [&](auto ks_tag, const ConvProblem& p, const ConvProblem* pn) {
+    // One branch (problem p, KS taps) of tile `t`: all C_in chunks, then its epilogue.
+    // (pn, tn) = the phase that follows this branch's last chunk -- the next branch of the same tile,
+    // or the first branch of the block's next tile -- or pn == nullptr at the very end.
+    auto run_branch = [&](auto ks_tag, auto pi_tag, auto pn_tag, const Tile& t, const bool next_valid, const Tile& tn) {
         constexpr int KS = decltype(ks_tag)::value;
+        constexpr int PI = decltype(pi_tag)::value;   // index of this branch's problem in a.p[]
+        constexpr int PN = decltype(pn_tag)::value;   // index of the problem whose window follows
         constexpr int NG = KS * GPC;
+        const ConvProblem& p = a.p[PI];               // constant index: stays in the kernarg segment
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, (unsigned)(KS * a.Gp) * wbytes_group);
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + batch_off, tensor_bytes);
         const int dilS = p.dil * S;
         // Output / residual element (m, r) of this lane sits at ovoff + (m*32 + (r&3) + 8*(r>>2)) rows:
         // the row part goes into the scalar offset, rows >= L fall outside num_records (store dropped,
         // load 0), lanes with co >= C_out get an out-of-range ovoff.  A branch without residual uses a
         // zero-length descriptor, whose loads return 0.
-        const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + batch_off, tensor_bytes);
-        const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + batch_off : p.y, (p.res && !(ablate & 8)) ? tensor_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + t.batch_off, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + t.batch_off : p.y, (p.res && !(ablate & 8)) ? tensor_bytes : 0u);
         constexpr int RPG = (MT * 16 + NG - 1) / NG;     // residual loads issued per MFMA group
         float resv[MT * 16];
-        auto res_load = [&](int idx) {
+        auto res_load = [&](int idx, unsigned voff) {
             const int m = idx / 16, r = idx % 16;
-            resv[idx] = buf_load1(rr, ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+            resv[idx] = buf_load1(rr, voff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
         };
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -131,62 +151,95 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
 
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const bool last = chunk + 1 == n_chunks;
-            const bool has_next = !last || pn != nullptr;
-            // the window staged during this chunk: next chunk of this branch, or chunk 0 of the next one
-            const ConvProblem& q = last && pn ? *pn : p;
-            const __amdgpu_buffer_rsrc_t xrn = last && pn ? make_rsrc(q.x + batch_off, tensor_bytes) : xr;
-            const int Rn = T_BLK + (q.ks - 1) * q.dil;
-            const unsigned vbn = stage_vbase(i0 - q.pad_left, last ? 0 : (chunk + 1) * CIC);
+            const bool has_next = !last || next_valid;
+            // the phase that follows: next chunk of this branch, or chunk 0 of (a.p[PN], tn)
+            const bool cross = last && next_valid;
+            const float* xq = cross ? a.p[PN].x + tn.batch_off : p.x + t.batch_off;
+            const f32x4* wq = cross ? a.p[PN].wp : p.wp;
+            const int ksq = cross ? a.p[PN].ks : KS;
+            const int dilq = cross ? a.p[PN].dil : p.dil;
+            const int padq = cross ? a.p[PN].pad_left : p.pad_left;
+            const int i0q = cross ? tn.i0 : t.i0;
+            const __amdgpu_buffer_rsrc_t xrn = make_rsrc(xq, tensor_bytes);
+            const __amdgpu_buffer_rsrc_t wrn = make_rsrc(wq, (unsigned)(ksq * a.Gp) * wbytes_group);
+            const int Rn = T_BLK + (ksq - 1) * dilq;
+            const unsigned vbn = stage_vbase(i0q - padq, last ? 0 : (chunk + 1) * CIC);
             const unsigned wsoff0 = (unsigned)(chunk * GPC) * wbytes_group;
+            const unsigned wsoffn = last ? 0u : (unsigned)((chunk + 1) * GPC) * wbytes_group;
+            const unsigned wvoffn = cross ? tn.wvoff : t.wvoff;
 
             auto a_ptr = [&](int n) { return aptr + (n / GPC) * dilS + 8 * (n % GPC); };
-            auto b_load = [&](int n) {
-                return buf_load4(wr, wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
+            auto b_load = [&](int n, unsigned voff_next) {   // group n of this phase, or group n-NG of the next one
+                if (n < NG)
+                    return buf_load4(wr, t.wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
+                return buf_load4(wrn, voff_next, wsoffn + (unsigned)(n - NG) * wbytes_group);   // n-NG < DB <= GPC: tap 0
             };
-            f32x4 bw[DB + 1];
             f32x4 av[2][MT];
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
-                if (d < NG) bw[d] = b_load(d);
-#pragma unroll
             for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(a_ptr(0) + m * 32 * S);
+            // Per group: 4*MT MFMAs of group n, and -- independent of them -- the requests for later
+            // groups: MT LDS reads (A of n+1), one weight fragment (n+DB), one staging quad, RPG
+            // residual words.  All of them are issued unconditionally (a request that is not needed
+            // carries an out-of-range offset and returns 0 without touching memory), so the group is
+            // one basic block and sched_group_barrier can slot ONE request behind each MFMA: every
+            // request then issues in the 64-cycle shadow of an MFMA instead of piling up at the
+            // group boundary.
+            const unsigned vbn_eff = has_next ? vbn : kOobOffset;
+            const unsigned res_voff = last ? t.ovoff : kOobOffset;
+            const unsigned wvoffn_eff = has_next ? wvoffn : kOobOffset;
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
-                if (n < NQ && has_next) stage_load_one(n, xrn, vbn);
-                if (last) {
+                if (n < NQ) stage_load_one(n, xrn, vbn_eff);
 #pragma unroll
-                    for (int j = 0; j < RPG; ++j)
-                        if (n * RPG + j < MT * 16) res_load(n * RPG + j);
-                }
-                if (n + DB < NG) bw[(n + DB) % (DB + 1)] = b_load(n + DB);
+                for (int j = 0; j < RPG; ++j)
+                    if (n * RPG + j < MT * 16) res_load(n * RPG + j, res_voff);
+                bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
                 if (n + 1 < NG) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
                         av[(n + 1) & 1][m] = *reinterpret_cast<const f32x4*>(a_ptr(n + 1) + m * 32 * S);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n & 1][m][e], bw[n % (DB + 1)][e], acc[m], 0, 0, 0);
+                // schedule: MFMA, request, MFMA, request, ...  (masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read)
+                {
+                    constexpr int n_ds = MT;
+                    const int n_vm = 1 + (n < NQ ? 1 : 0) + ((n * RPG < MT * 16) ? ((MT * 16 - n * RPG) < RPG ? (MT * 16 - n * RPG) : RPG) : 0);
+                    int ds_left = (n + 1 < NG) ? n_ds : 0, vm_left = n_vm;
+#pragma unroll
+                    for (int k = 0; k < 4 * MT; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (ds_left > 0) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); --ds_left; }
+                        else if (vm_left > 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); --vm_left; }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (has_next) {
 #pragma unroll
-                for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn);
+            for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn_eff);
+            // the next phase expects its groups 0..DB-1 in ring slots 0..DB-1: they were loaded into
+            // slots (NG + d) % (DB+1)
+            {
+                f32x4 tmp[DB];
+#pragma unroll
+                for (int d = 0; d < DB; ++d) tmp[d] = bw[(NG + d) % (DB + 1)];
+#pragma unroll
+                for (int d = 0; d < DB; ++d) bw[d] = tmp[d];
             }
 
             if (last) {
                 // epilogue of this branch. D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                const float bias = p.bias[co_lane < a.C_out ? co_lane : 0];
+                const float bias = p.bias[t.co_lane < a.C_out ? t.co_lane : 0];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[m][r] + bias + resv[m * 16 + r];
                         if (!(ablate & 4) || v == 1.2345e-30f)
-                            buf_store1(v, yr, ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+                            buf_store1(v, yr, t.ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
                     }
                 }
             }
@@ -198,20 +251,37 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
         }
     };
 
-    {   // prologue: the first window (the only staging latency a block ever exposes)
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    Tile t = make_tile(tile);
+    {   // prologue: the first window and the first weight fragments (the only latencies a block exposes)
         const ConvProblem& p0 = a.p[2];
         const int R0 = T_BLK + (p0.ks - 1) * p0.dil;
-        const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p0.x + batch_off, tensor_bytes);
-        const unsigned vb0 = stage_vbase(i0 - p0.pad_left, 0);
+        const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p0.x + t.batch_off, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t wr0 = make_rsrc(p0.wp, (unsigned)(p0.ks * a.Gp) * wbytes_group);
+        const unsigned vb0 = stage_vbase(t.i0 - p0.pad_left, 0);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) stage_load_one(i, xr0, vb0);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) bw[d] = buf_load4(wr0, t.wvoff, (unsigned)d * wbytes_group);
         stage_write_all(R0);
         __syncthreads();
     }
-    // branches heaviest first: p[2] (KC taps), p[1] (KB), p[0] (KA)
-    run_branch(std::integral_constant<int, KC>{}, a.p[2], &a.p[1]);
-    run_branch(std::integral_constant<int, KB>{}, a.p[1], &a.p[0]);
-    run_branch(std::integral_constant<int, KA>{}, a.p[0], nullptr);
+    // persistent over tiles; branches heaviest first: p[2] (KC taps), p[1] (KB), p[0] (KA)
+    for (;;) {
+        const int tile_next = tile + (int)gridDim.x;
+        const bool more = tile_next < n_tiles;
+        const Tile tn = make_tile(more ? tile_next : tile);
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
+        run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
+        run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
+        if (!more) break;
+        tile = tile_next;
+        t = tn;
+    }
 }
 
 // True when the grouped launch `a` (nz problems) can take the MRF kernel.
@@ -244,7 +314,19 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     a.ablate = ablate_env;
     const size_t lds_bytes = (size_t)(t.T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
     const int n_t = (a.L_out + t.T_BLK - 1) / t.T_BLK;
-    dim3 grid((unsigned)(n_t * a.n_co_blk), (unsigned)a.B, 1u), block(256);
+    const long long n_tiles = (long long)n_t * a.n_co_blk * a.B;
+    if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    // Persistent grid: at most `per_cu` blocks per CU, then evened out so that every block walks the
+    // same number of tiles (+-1): 1000 tiles on 256 CUs x 3 -> 2 rounds -> 500 blocks of 2 tiles.
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : 2;   // 172-202 VGPRs: two blocks (8 waves) per CU
+    long long g = (long long)n_cu * per_cu;
+    if (g > n_tiles) g = n_tiles;
+    const long long rounds = (n_tiles + g - 1) / g;
+    g = (n_tiles + rounds - 1) / rounds;
+    dim3 grid((unsigned)g, 1u, 1u), block(256);
 #define IRIS_MRF_LAUNCH(WT_, WC_, CIC_, DB_)                                                     \
     do {                                                                                          \
         auto kfn = mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, DB_, 3, 7, 11>;                              \
