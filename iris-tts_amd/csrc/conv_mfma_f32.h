@@ -67,6 +67,7 @@ struct ConvLaunch {
     int in_act;
     int x_channels_first;
     float slope;
+    unsigned long long* dbg;  // diagnostics only (stamp builds): 7 accumulators, else nullptr
     int ablate;          // diagnostics only (env IRIS_HIFIGAN_ABLATE): 1 skip staging, 2 weights from one
                          // address, 4 skip epilogue stores, 8 skip residual read.  Results are wrong.
     int z_serial;        // 1: every block loops over all nz_serial problems of its tile (equal-cost blocks)

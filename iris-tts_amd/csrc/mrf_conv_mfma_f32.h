@@ -19,10 +19,21 @@
 //     one per group gives each of them DB groups (~DB*512 cycles) of flight time before any wave
 //     can stall on it.
 #pragma once
+#include <stdio.h>
 #include <type_traits>
 #include "conv_mfma_f32.h"
 
 namespace iris {
+
+#ifdef IRIS_MRF_DIAG
+#define IRIS_MRF_ABLATE(a) ((a).ablate)
+#else
+#define IRIS_MRF_ABLATE(a) 0
+#endif
+
+#ifndef IRIS_MRF_MINWAVES
+#define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
+#endif
 
 constexpr int kMrfSpanMax = 50;  // (ks-1)*dil of the widest supported conv: k=11, d=5
 
@@ -45,10 +56,35 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned
 __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
+}
 constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
 
+// 4x4 transpose across the 4 lanes of a quad (lane&3) and 4 registers, two DPP butterfly stages:
+// afterwards register e of lane j holds what register j of lane e held.  Used by the epilogue: the
+// MFMA leaves one output column (channel) per lane and 4 consecutive rows in registers; after the
+// transpose a lane owns 4 consecutive channels of ONE row = one 16-byte store.
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    {   // lanes l <-> l^1 exchange (r0,r1) and (r2,r3) off-diagonals
+        const float s01 = b0 ? r0 : r1, s23 = b0 ? r2 : r3;
+        const float g01 = quad_perm<0xB1>(s01), g23 = quad_perm<0xB1>(s23);   // quad_perm [1,0,3,2]
+        if (b0) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
+    }
+    {   // lanes l <-> l^2 exchange (r0,r2) and (r1,r3) off-diagonals
+        const float s02 = b1 ? r0 : r2, s13 = b1 ? r1 : r3;
+        const float g02 = quad_perm<0x4E>(s02), g13 = quad_perm<0x4E>(s13);   // quad_perm [2,3,0,1]
+        if (b1) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
+    }
+}
+
 template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC>
-__global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
+__global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = CIC + 4;
     constexpr int QPR = CIC / 4;
@@ -65,11 +101,15 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
     const int n_t = (L + T_BLK - 1) / T_BLK;
     const int tiles_per_item = n_t * a.n_co_blk;
     const int n_tiles = tiles_per_item * a.B;
-    const unsigned wbytes_group = (a.ablate & 2) ? 0u : (unsigned)a.n_ct * 64u * 16u;  // bytes per (tap, group)
+    const unsigned wbytes_group = (IRIS_MRF_ABLATE(a) & 2) ? 0u : (unsigned)a.n_ct * 64u * 16u;  // bytes per (tap, group)
     const unsigned tap_bytes = (unsigned)a.Gp * wbytes_group;
     const float* aptr = lds + (wt * MT * 32 + lo) * S + 4 * hi;
     const float slope = a.slope;
-    const int ablate = a.ablate;
+#ifdef IRIS_MRF_DIAG
+    const int ablate = a.ablate;          // diagnostic builds: runtime ablation switches
+#else
+    constexpr int ablate = 0;
+#endif
     const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
 
     // A tile = (batch item, time tile, C_out block).  Everything a phase needs to know about it:
@@ -77,8 +117,9 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
         size_t batch_off;   // elements to this batch item's [L, C] tensor
         int i0;             // first output row
         unsigned wvoff;     // this lane's byte offset inside a (tap, group) of packed weights
-        unsigned ovoff;     // this lane's byte offset of output element (m=0, r=0), or out of range
-        int co_lane;
+        unsigned ovoff4;    // byte offset of this lane's 16-byte output piece for (m=0, g=0): row
+                            // i0 + wave rows + (lo&3) + 4*hi, channels co4..co4+3; out of range if unused
+        int co4;
     };
     auto make_tile = [&](int tile) {
         Tile t;
@@ -90,9 +131,9 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
         t.batch_off = (size_t)b * L * C;
         t.i0 = tile_t * T_BLK;
         t.wvoff = (unsigned)(ct * 64 + lane) * 16u;
-        t.co_lane = ct * 32 + lo;
-        t.ovoff = (active && t.co_lane < a.C_out)
-                      ? (unsigned)((t.i0 + wt * MT * 32 + 4 * hi) * C + t.co_lane) * 4u : kOobOffset;
+        t.co4 = ct * 32 + 4 * (lo >> 2);
+        t.ovoff4 = (active && t.co4 < a.C_out)
+                       ? (unsigned)((t.i0 + wt * MT * 32 + (lo & 3) + 4 * hi) * C + t.co4) * 4u : kOobOffset;
         return t;
     };
 
@@ -114,9 +155,33 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
     auto stage_write_all = [&](int R) {      // LeakyReLU on the way in (hifigan_pretrained.py:66,68)
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
-            if (r_lane + i * RPI < R) *reinterpret_cast<f32x4*>(lds_wr + i * RPI * S) = lrelu4(st[i], slope);
+            if (r_lane + i * RPI < R) {
+                // 0 <= slope <= 1 (checked by the host): LeakyReLU(x) = max(x, slope*x), 2 VALU ops per value
+                f32x4 v = st[i];
+                v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                *reinterpret_cast<f32x4*>(lds_wr + i * RPI * S) = v;
+            }
     };
 
+#ifdef IRIS_MRF_STAMPS
+    // diagnostic build only: per-wave cycle totals of [0] MFMA loops, [1] epilogues, [2] barrier before
+    // the LDS write, [3] LDS write, [4] barrier after it, [5] everything (kernel entry to exit)
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    const unsigned long long t_entry = stamp();
+#define IRIS_STAMP(var) const unsigned long long var = stamp()
+#define IRIS_SEG(i, a_, b_) seg[i] += (b_) - (a_)
+#else
+#define IRIS_STAMP(var)
+#define IRIS_SEG(i, a_, b_)
+#endif
     f32x16 acc[MT];
     f32x4 bw[DB + 1];     // ring of weight fragments; groups 0..DB-1 of a phase are requested by the
                           // phase before it (or by the prologue)
@@ -132,17 +197,21 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
         const ConvProblem& p = a.p[PI];               // constant index: stays in the kernarg segment
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, (unsigned)(KS * a.Gp) * wbytes_group);
         const int dilS = p.dil * S;
-        // Output / residual element (m, r) of this lane sits at ovoff + (m*32 + (r&3) + 8*(r>>2)) rows:
-        // the row part goes into the scalar offset, rows >= L fall outside num_records (store dropped,
-        // load 0), lanes with co >= C_out get an out-of-range ovoff.  A branch without residual uses a
+        // Output / residual piece (m, g) of this lane sits at ovoff4 + (m*32 + 8g) rows: the row part
+        // goes into the scalar offset, rows >= L fall outside num_records (store dropped, load 0), lanes
+        // with channels >= C_out get an out-of-range ovoff4.  A branch without residual uses a
         // zero-length descriptor, whose loads return 0.
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + t.batch_off, tensor_bytes);
         const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + t.batch_off : p.y, (p.res && !(ablate & 8)) ? tensor_bytes : 0u);
-        constexpr int RPG = (MT * 16 + NG - 1) / NG;     // residual loads issued per MFMA group
-        float resv[MT * 16];
-        auto res_load = [&](int idx, unsigned voff) {
-            const int m = idx / 16, r = idx % 16;
-            resv[idx] = buf_load1(rr, voff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+        // loaded here, not in the epilogue: vmcnt retires in order, so a load issued in the epilogue
+        // would have to wait for every prefetch issued by the last MFMA groups
+        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (t.co4 < a.C_out ? t.co4 : 0));
+        constexpr int NRES = MT * 4;                     // 16-byte residual pieces per lane: (m, g)
+        constexpr int RPG = (NRES + NG - 1) / NG;        // residual loads issued per MFMA group
+        f32x4 resv[NRES];
+        auto res_load = [&](int idx, unsigned voff) {    // piece (m, g): rows m*32 + 8g + (lo&3) + 4hi
+            const int m = idx / 4, g = idx % 4;
+            resv[idx] = buf_load4(rr, voff, (unsigned)((m * 32 + 8 * g) * C) * 4u);
         };
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -175,6 +244,7 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
                 return buf_load4(wrn, voff_next, wsoffn + (unsigned)(n - NG) * wbytes_group);   // n-NG < DB <= GPC: tap 0
             };
             f32x4 av[2][MT];
+            IRIS_STAMP(ts0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(a_ptr(0) + m * 32 * S);
             // Per group: 4*MT MFMAs of group n, and -- independent of them -- the requests for later
@@ -185,14 +255,14 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
             // request then issues in the 64-cycle shadow of an MFMA instead of piling up at the
             // group boundary.
             const unsigned vbn_eff = has_next ? vbn : kOobOffset;
-            const unsigned res_voff = last ? t.ovoff : kOobOffset;
+            const unsigned res_voff = last ? t.ovoff4 : kOobOffset;
             const unsigned wvoffn_eff = has_next ? wvoffn : kOobOffset;
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
                 if (n < NQ) stage_load_one(n, xrn, vbn_eff);
 #pragma unroll
                 for (int j = 0; j < RPG; ++j)
-                    if (n * RPG + j < MT * 16) res_load(n * RPG + j, res_voff);
+                    if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
                 bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
                 if (n + 1 < NG) {
 #pragma unroll
@@ -207,7 +277,7 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
                 // schedule: MFMA, request, MFMA, request, ...  (masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read)
                 {
                     constexpr int n_ds = MT;
-                    const int n_vm = 1 + (n < NQ ? 1 : 0) + ((n * RPG < MT * 16) ? ((MT * 16 - n * RPG) < RPG ? (MT * 16 - n * RPG) : RPG) : 0);
+                    const int n_vm = 1 + (n < NQ ? 1 : 0) + ((n * RPG < NRES) ? ((NRES - n * RPG) < RPG ? (NRES - n * RPG) : RPG) : 0);
                     int ds_left = (n + 1 < NG) ? n_ds : 0, vm_left = n_vm;
 #pragma unroll
                     for (int k = 0; k < 4 * MT; ++k) {
@@ -220,6 +290,8 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
             }
 #pragma unroll
             for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn_eff);
+            IRIS_STAMP(ts1);
+            IRIS_SEG(0, ts0, ts1);
             // the next phase expects its groups 0..DB-1 in ring slots 0..DB-1: they were loaded into
             // slots (NG + d) % (DB+1)
             {
@@ -231,22 +303,33 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
             }
 
             if (last) {
-                // epilogue of this branch. D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-                const float bias = p.bias[t.co_lane < a.C_out ? t.co_lane : 0];
+                // Epilogue of this branch.  D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2)
+                // + 4*(lane>>5).  Registers 4g..4g+3 are 4 consecutive rows: transposing them across the
+                // lane quad gives each lane 4 consecutive channels of one row -> 16-byte stores, 4x fewer
+                // store instructions (the store tail is issue-bound, not bandwidth-bound).
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[m][r] + bias + resv[m * 16 + r];
-                        if (!(ablate & 4) || v == 1.2345e-30f)
-                            buf_store1(v, yr, t.ovoff, (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C) * 4u);
+                    for (int g = 0; g < 4; ++g) {
+                        float r0 = acc[m][4 * g + 0], r1 = acc[m][4 * g + 1], r2 = acc[m][4 * g + 2], r3 = acc[m][4 * g + 3];
+                        quad_transpose4(r0, r1, r2, r3, lane);
+                        f32x4 v = {r0, r1, r2, r3};
+                        v = (v + bias4) + resv[m * 4 + g];
+                        if (!(ablate & 4) || v.x == 1.2345e-30f)
+                            buf_store4(v, yr, t.ovoff4, (unsigned)((m * 32 + 8 * g) * C) * 4u);
                     }
                 }
             }
+            IRIS_STAMP(ts2);
+            IRIS_SEG(1, ts1, ts2);
             if (has_next) {
                 __syncthreads();          // every wave is done reading this chunk's window
+                IRIS_STAMP(ts3);
                 stage_write_all(Rn);
+                IRIS_STAMP(ts4);
                 __syncthreads();
+                IRIS_STAMP(ts5);
+                IRIS_SEG(2, ts2, ts3); IRIS_SEG(3, ts3, ts4); IRIS_SEG(4, ts4, ts5);
             }
         }
     };
@@ -282,6 +365,13 @@ __global__ void __launch_bounds__(256, 2) mrf_conv_mfma_f32_kernel(const ConvLau
         tile = tile_next;
         t = tn;
     }
+#ifdef IRIS_MRF_STAMPS
+    seg[5] = stamp() - t_entry;
+    if (lane == 0 && a.dbg) {
+        for (int i = 0; i < 6; ++i) atomicAdd(a.dbg + i, seg[i]);
+        atomicAdd(a.dbg + 6, 1ull);
+    }
+#endif
 }
 
 // True when the grouped launch `a` (nz problems) can take the MRF kernel.
@@ -291,7 +381,7 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
     if (a.n_idx != a.L_out) return false;
     if ((uint64_t)a.L_in * a.C_in * 4u >= 0x7fffffffull) return false;       // 32-bit buffer offsets
     if (nz != 3 || a.p[0].ks != 3 || a.p[1].ks != 7 || a.p[2].ks != 11) return false;   // the V1 MRF
-    if (a.in_act != IN_ACT_LRELU) return false;
+    if (a.in_act != IN_ACT_LRELU || !(a.slope >= 0.f && a.slope <= 1.f)) return false;
     for (int j = 0; j < nz; ++j) {
         if (packed_conv1d_floats(a.C_in, a.C_out, a.p[j].ks) * 4u >= 0x7fffffffull) return false;
         const int ks = a.p[j].ks;
@@ -321,7 +411,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
                                  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
-    const int per_cu = per_cu_env > 0 ? per_cu_env : 2;   // 172-202 VGPRs: two blocks (8 waves) per CU
+    const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;   // blocks (of 4 waves) per CU
     long long g = (long long)n_cu * per_cu;
     if (g > n_tiles) g = n_tiles;
     const long long rounds = (n_tiles + g - 1) / g;
@@ -340,10 +430,30 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     } while (0)
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
     do { if (db_env >= 6) IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 6); else IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 4); } while (0)
+#ifdef IRIS_MRF_STAMPS
+    static unsigned long long* dbg_dev = nullptr;
+    if (!dbg_dev) { if (hipMalloc(&dbg_dev, 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
+    (void)hipMemsetAsync(dbg_dev, 0, 8 * sizeof(unsigned long long), stream);
+    a.dbg = dbg_dev;
+#endif
     if (t.WT == 4 && t.CIC == 32)      IRIS_MRF_LAUNCH_DB(4, 1, 32);
     else if (t.WT == 4)                IRIS_MRF_LAUNCH_DB(4, 1, 64);
     else if (t.WT == 2)                IRIS_MRF_LAUNCH_DB(2, 2, 64);
     else                               IRIS_MRF_LAUNCH_DB(1, 4, 64);
+#ifdef IRIS_MRF_STAMPS
+    {   // diagnostic build: synchronous read-back of the per-wave cycle shares
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
+        const double tot = (double)h[5], nw = (double)h[6];
+        double mfma_cyc = 0;   // ideal MFMA cycles per wave: 64 per MFMA
+        for (int j = 0; j < nz; ++j) mfma_cyc += 2.0 * a.p[j].ks * (a.C_in / 2.0);
+        mfma_cyc *= 64.0 * (double)n_tiles / (double)g;
+        fprintf(stderr, "[stamps] C=%d L=%d grid=%lld waves=%.0f cyc/wave=%.0f ideal_mfma=%.0f (%.3f) | mfma_loop %.3f epilogue %.3f bar1 %.3f ldswrite %.3f bar2 %.3f other %.3f\n",
+                a.C_in, a.L_in, g, nw, tot / nw, mfma_cyc, mfma_cyc / (tot / nw), h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot,
+                1.0 - (h[0] + h[1] + h[2] + h[3] + h[4]) / tot);
+    }
+#endif
 #undef IRIS_MRF_LAUNCH_DB
 #undef IRIS_MRF_LAUNCH
     return hipGetLastError();
