@@ -38,6 +38,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0          # spec; 6.3 TB/s achievable
 
 
+def committed_traffic(batch, frames):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 correction applied:
+    profiles/r*_hbm_traffic.json).  PMC counters cannot be collected from inside this process, so the
+    figure is the committed measurement of the same workload, or None when the workload differs."""
+    files = sorted((REPO / "profiles").glob("r*_hbm_traffic.json"))
+    if not files or (batch, frames) != (1, 1000):
+        return None
+    try:
+        return json.loads(files[-1].read_text())["mrf_traffic_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, sd, mel, budget_s=20.0):
     """Times the oracle's torch-fp32 forward (the arithmetic the reference's PyTorch twin runs) on the
     host cores.  Bounded: 1 warm-up on a short clip, then whole utterances until ~budget_s is spent
@@ -159,9 +173,9 @@ def main():
         dom = by_kind["mrf_resblock_conv"]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        roofline = {"kernel": "conv_mfma_f32_kernel (MRF ResBlock Conv1d groups, 24 launches/forward)",
+        roofline = {"kernel": "mrf_conv_mfma_f32_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": committed_traffic(B, T),
                     "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
                     "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
                     "bytes_per_launch": dom["bytes"] / dom["n"],

@@ -259,11 +259,13 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             const unsigned wvoffn_eff = has_next ? wvoffn : kOobOffset;
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
-                if (n < NQ) stage_load_one(n, xrn, vbn_eff);
+                if (!(ablate & 16)) {
+                    if (n < NQ) stage_load_one(n, xrn, vbn_eff);
 #pragma unroll
-                for (int j = 0; j < RPG; ++j)
-                    if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
-                bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
+                    for (int j = 0; j < RPG; ++j)
+                        if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
+                }
+                if (!(ablate & 32)) bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
                 if (n + 1 < NG) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
