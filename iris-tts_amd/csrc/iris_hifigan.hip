@@ -458,8 +458,11 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops,
                                4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
+                static const int stop_after = [] { const char* e = getenv("IRIS_HIFIGAN_STOP_AFTER_MRF"); return e ? atoi(e) : -1; }();
+                if (stop_after >= 0 && (int)i * 100 + 2 * m + half > stop_after) { h->n_rec = prof.idx; return IRIS_HIFIGAN_OK; }   // debugging aid
                 static const int use_mrf = [] { const char* e = getenv("IRIS_HIFIGAN_MRF"); return e ? atoi(e) : 1; }();
-                if (use_mrf && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
+                static const int mrf_stage_mask = [] { const char* e = getenv("IRIS_HIFIGAN_MRF_STAGES"); return e ? atoi(e) : 0xff; }();
+                if (use_mrf && ((mrf_stage_mask >> i) & 1) && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
                 else                                         HIP_TRY(launch_conv(a, nk, stream));
                 TRY(prof.end());
             }

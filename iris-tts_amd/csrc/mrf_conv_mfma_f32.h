@@ -61,28 +61,6 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc,
 }
 constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
 
-// 4x4 transpose across the 4 lanes of a quad (lane&3) and 4 registers, two DPP butterfly stages:
-// afterwards register e of lane j holds what register j of lane e held.  Used by the epilogue: the
-// MFMA leaves one output column (channel) per lane and 4 consecutive rows in registers; after the
-// transpose a lane owns 4 consecutive channels of ONE row = one 16-byte store.
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ void quad_transpose4(float& r0, float& r1, float& r2, float& r3, int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    {   // lanes l <-> l^1 exchange (r0,r1) and (r2,r3) off-diagonals
-        const float s01 = b0 ? r0 : r1, s23 = b0 ? r2 : r3;
-        const float g01 = quad_perm<0xB1>(s01), g23 = quad_perm<0xB1>(s23);   // quad_perm [1,0,3,2]
-        if (b0) { r0 = g01; r2 = g23; } else { r1 = g01; r3 = g23; }
-    }
-    {   // lanes l <-> l^2 exchange (r0,r2) and (r1,r3) off-diagonals
-        const float s02 = b1 ? r0 : r2, s13 = b1 ? r1 : r3;
-        const float g02 = quad_perm<0x4E>(s02), g13 = quad_perm<0x4E>(s13);   // quad_perm [2,3,0,1]
-        if (b1) { r0 = g02; r1 = g13; } else { r2 = g02; r3 = g13; }
-    }
-}
-
 template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC>
 __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -118,7 +96,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         int i0;             // first output row
         unsigned wvoff;     // this lane's byte offset inside a (tap, group) of packed weights
         unsigned ovoff4;    // byte offset of this lane's 16-byte output piece for (m=0, g=0): row
-                            // i0 + wave rows + (lo&3) + 4*hi, channels co4..co4+3; out of range if unused
+                            // i0 + wave rows + lo, channels co4..co4+3 (co4 = tile base + 4*hi); out of range if unused
         int co4;
     };
     auto make_tile = [&](int tile) {
@@ -131,9 +109,9 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         t.batch_off = (size_t)b * L * C;
         t.i0 = tile_t * T_BLK;
         t.wvoff = (unsigned)(ct * 64 + lane) * 16u;
-        t.co4 = ct * 32 + 4 * (lo >> 2);
+        t.co4 = ct * 32 + 4 * hi;
         t.ovoff4 = (active && t.co4 < a.C_out)
-                       ? (unsigned)((t.i0 + wt * MT * 32 + (lo & 3) + 4 * hi) * C + t.co4) * 4u : kOobOffset;
+                       ? (unsigned)((t.i0 + wt * MT * 32 + lo) * C + t.co4) * 4u : kOobOffset;
         return t;
     };
 
@@ -197,7 +175,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         const ConvProblem& p = a.p[PI];               // constant index: stays in the kernarg segment
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, (unsigned)(KS * a.Gp) * wbytes_group);
         const int dilS = p.dil * S;
-        // Output / residual piece (m, g) of this lane sits at ovoff4 + (m*32 + 8g) rows: the row part
+        // Output / residual piece (m, g) of this lane sits at ovoff4 + m*32 rows + 8g channels: that part
         // goes into the scalar offset, rows >= L fall outside num_records (store dropped, load 0), lanes
         // with channels >= C_out get an out-of-range ovoff4.  A branch without residual uses a
         // zero-length descriptor, whose loads return 0.
@@ -205,13 +183,16 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + t.batch_off : p.y, (p.res && !(ablate & 8)) ? tensor_bytes : 0u);
         // loaded here, not in the epilogue: vmcnt retires in order, so a load issued in the epilogue
         // would have to wait for every prefetch issued by the last MFMA groups
-        const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (t.co4 < a.C_out ? t.co4 : 0));
+        f32x4 bias4[4];                                  // channels co4 + 8g + {0..3}
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + (t.co4 + 8 * g < a.C_out ? t.co4 + 8 * g : 0));
         constexpr int NRES = MT * 4;                     // 16-byte residual pieces per lane: (m, g)
         constexpr int RPG = (NRES + NG - 1) / NG;        // residual loads issued per MFMA group
         f32x4 resv[NRES];
-        auto res_load = [&](int idx, unsigned voff) {    // piece (m, g): rows m*32 + 8g + (lo&3) + 4hi
+        auto res_load = [&](int idx, unsigned voff) {    // piece (m, g): row m*32 + lo, channels co4 + 8g..+3
             const int m = idx / 4, g = idx % 4;
-            resv[idx] = buf_load4(rr, voff, (unsigned)((m * 32 + 8 * g) * C) * 4u);
+            resv[idx] = buf_load4(rr, voff, (unsigned)(m * 32 * C + 8 * g) * 4u);
         };
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -275,7 +256,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n & 1][m][e], bw[n % (DB + 1)][e], acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[n % (DB + 1)][e], av[n & 1][m][e], acc[m], 0, 0, 0);
                 // schedule: MFMA, request, MFMA, request, ...  (masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read)
                 {
                     constexpr int n_ds = MT;
@@ -305,22 +286,35 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             }
 
             if (last) {
-                // Epilogue of this branch.  D layout of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2)
-                // + 4*(lane>>5).  Registers 4g..4g+3 are 4 consecutive rows: transposing them across the
-                // lane quad gives each lane 4 consecutive channels of one row -> 16-byte stores, 4x fewer
-                // store instructions (the store tail is issue-bound, not bandwidth-bound).
+                // Epilogue of this branch.  The MFMA was issued as D = W_frag x X_frag, i.e. D[co][t]: a
+                // lane holds ONE time step (col = lane&31) and, in registers 4g..4g+3, the 4 consecutive
+                // channels 8g + 4*(lane>>5) + {0..3} -- one 16-byte piece of the channels-last row, so the
+                // 16-byte stores need no cross-lane transpose (the store tail is issue-bound: 8 dwordx4
+                // stores per branch instead of 32 dword stores).
+                // Bias and residual are added IN PLACE and all stores are then issued straight from
+                // registers that nothing rewrites before the next branch starts.  Storing from
+                // short-lived temporaries is NOT safe here: hipcc reuses a buffer_store_dwordx4's data
+                // registers two instructions later, and with the store path busy (8 stores per wave, two
+                // blocks per CU) stores were observed to pick up the NEXT piece's values in lanes 12-15
+                // of each 16-lane row -- wrong results only when two blocks shared a CU.
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[m][4 * g + e] = (acc[m][4 * g + e] + bias4[g][e]) + resv[m * 4 + g][e];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float r0 = acc[m][4 * g + 0], r1 = acc[m][4 * g + 1], r2 = acc[m][4 * g + 2], r3 = acc[m][4 * g + 3];
-                        quad_transpose4(r0, r1, r2, r3, lane);
-                        f32x4 v = {r0, r1, r2, r3};
-                        v = (v + bias4) + resv[m * 4 + g];
+                        const f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
                         if (!(ablate & 4) || v.x == 1.2345e-30f)
-                            buf_store4(v, yr, t.ovoff4, (unsigned)((m * 32 + 8 * g) * C) * 4u);
+                            buf_store4(v, yr, t.ovoff4, (unsigned)(m * 32 * C + 8 * g) * 4u);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             IRIS_STAMP(ts2);
             IRIS_SEG(1, ts1, ts2);

@@ -1,0 +1,81 @@
+"""Chunked ("streaming") vocoding of long mels (BASELINE.json configs[4]).
+
+The reference has no streaming (``TTSPipeline`` is a stub, src/iris/model.py:17-27; every caller hands
+the vocoder a whole utterance).  The generator is, however, a finite-receptive-field convolution
+stack: an output sample depends on the mel only within +-12.64 frames (3235 samples: probed on the
+reference).  A chunk of ``chunk_frames`` frames vocoded together with
+``halo_frames >= 13`` frames of context on each side therefore yields exactly the samples the one-shot
+forward produces for that chunk: the zero padding the layers apply at the window edges can only reach
+samples inside the halo, which are dropped.
+
+``plan_chunks`` is pure host logic; ``StreamingVocoder`` drives any ``forward(mel_window) -> waveform``
+callable -- the GPU engine in production, the CPU oracle in the tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Iterator, List
+
+RECEPTIVE_FIELD_FRAMES = 13  # ceil(12.64); V1 config
+
+
+@dataclass(frozen=True)
+class Chunk:
+    """Frames [start, stop) are emitted; frames [win_start, win_stop) are vocoded."""
+
+    start: int
+    stop: int
+    win_start: int
+    win_stop: int
+
+    def emit_slice(self, hop: int) -> slice:
+        """Sample range of the window's waveform that belongs to [start, stop)."""
+        return slice((self.start - self.win_start) * hop, (self.stop - self.win_start) * hop)
+
+
+def plan_chunks(n_frames: int, chunk_frames: int = 256, halo_frames: int = RECEPTIVE_FIELD_FRAMES) -> List[Chunk]:
+    if n_frames < 0 or chunk_frames < 1 or halo_frames < 0:
+        raise ValueError("n_frames >= 0, chunk_frames >= 1 and halo_frames >= 0 are required")
+    chunks = []
+    for start in range(0, n_frames, chunk_frames):
+        stop = min(start + chunk_frames, n_frames)
+        chunks.append(Chunk(start, stop, max(0, start - halo_frames), min(n_frames, stop + halo_frames)))
+    return chunks
+
+
+class StreamingVocoder:
+    """Vocodes ``mel [B, n_mels, T]`` chunk by chunk.
+
+    ``forward`` maps a window ``[B, n_mels, W]`` to ``[B, hop*W]`` (e.g. ``GeneratorEngine.forward``);
+    inputs/outputs may be torch tensors or numpy arrays -- they are only sliced along the last axis.
+    """
+
+    def __init__(self, forward: Callable, hop_length: int = 256, chunk_frames: int = 256,
+                 halo_frames: int = RECEPTIVE_FIELD_FRAMES):
+        if halo_frames < RECEPTIVE_FIELD_FRAMES:
+            raise ValueError(
+                f"halo_frames={halo_frames} is smaller than the generator's receptive field "
+                f"({RECEPTIVE_FIELD_FRAMES} frames): chunk seams would differ from the one-shot output")
+        self.forward = forward
+        self.hop_length = hop_length
+        self.chunk_frames = chunk_frames
+        self.halo_frames = halo_frames
+
+    def stream(self, mel) -> Iterator:
+        """Yields the waveform of each chunk, ``[B, hop*(stop-start)]``, in order."""
+        if mel.ndim != 3:
+            raise ValueError(f"expected mel [B, n_mels, T], got shape {tuple(mel.shape)}")
+        for c in plan_chunks(mel.shape[2], self.chunk_frames, self.halo_frames):
+            wav = self.forward(mel[:, :, c.win_start:c.win_stop])
+            yield wav[:, c.emit_slice(self.hop_length)]
+
+    def infer(self, mel):
+        """Concatenation of ``stream(mel)``; equals the one-shot forward of the whole mel."""
+        parts = list(self.stream(mel))
+        if not parts:
+            return self.forward(mel)
+        if hasattr(parts[0], "detach"):
+            import torch
+            return torch.cat(parts, dim=1)
+        import numpy as np
+        return np.concatenate(parts, axis=1)

@@ -218,3 +218,104 @@ def test_profile_records_cover_algorithmic_work(dev):
     assert act_bytes == pytest.approx(4.0 * work["elements_per_frame"] * B * T, rel=1e-12)
     assert all(r["ms"] > 0 for r in recs)
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configurations at full size, and the drop-in wrappers
+# ------------------------------------------------------------------------------------------------
+def test_config2_full_size_matches_oracle(dev):
+    """configs[1]: batch 1, 80 x 1000 frames, fp32 -- the bench workload, against the torch oracle."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    mel = seeded_mel(1002, 1, 1000)
+    eng = GeneratorEngine(cfg, sd, dev)
+    got = eng.forward(torch.from_numpy(mel).to(dev)).cpu().numpy()
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel).numpy()[:, 0, :]
+    assert got.shape == (1, 256000)
+    assert np.abs(got - want).max() <= TOL_WAV
+    assert np.abs(got).max() <= 1.0 and np.abs(got).max() > 0.9      # tanh range is exercised
+    eng.close()
+
+
+def test_config3_batch32_properties(dev):
+    """configs[2] shape (batch 32 x 500 frames; fp32 here): too big for the CPU oracle in a test, so
+    it is checked through size-independent properties -- every item equals the same mel run alone
+    (bit-exact), two items match the oracle, output is finite and inside tanh's range."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    mel_np = seeded_mel(1003, 32, 500, log_mel=True)
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(mel_np).to(dev)
+    full = eng.forward(mel).clone()
+    assert full.shape == (32, 128000) and torch.isfinite(full).all() and full.abs().max() <= 1.0
+    for b in (0, 13, 31):
+        alone = eng.forward(mel[b:b + 1].contiguous())
+        assert torch.equal(alone[0], full[b])
+    folded = orc.to_torch_folded(sd)
+    for b in (5, 30):
+        want = orc.generator_forward_torch(folded, mel_np[b:b + 1]).numpy()[0, 0]
+        assert np.abs(full[b].cpu().numpy() - want).max() <= TOL_WAV
+    eng.close()
+
+
+def test_dropin_pretrained_module_on_gpu(tmp_path, manifest, golden, case_setup):
+    """iris.hifigan_pretrained: checkpoint containers, squeeze rules and dtypes as recorded from the
+    reference (tests/golden/manifest.json), numerics vs the reference's golden waveform."""
+    from iris import hifigan_pretrained as hp
+    cfg, sd = case_setup("v1_default_B2_T16")
+    g = golden("v1_default_B2_T16")
+    flat = tmp_path / "generator.ckpt"
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, flat)
+    gen = hp.HiFiGANGenerator(flat)
+    assert gen.device.type == "cuda" and gen.checkpoint_path == flat and hasattr(gen, "model")
+    out = gen(g["mel"])
+    assert out.dtype == np.float32 and np.abs(out - g["wav"][:, 0, :]).max() <= TOL_WAV
+    sem = manifest["wrapper_semantics"]
+    for shape_s, per_entry in sem.items():
+        if not shape_s.startswith("["):
+            continue
+        shape = tuple(int(v) for v in shape_s.strip("[]").split(","))
+        x = np.random.default_rng(0).standard_normal(shape)            # float64, like the recording
+        a = gen(x)
+        b = hp.infer_hifigan(x, sample_rate=22050, hop_length=256, checkpoint_path=flat)
+        assert list(a.shape) == per_entry["generator_call"]["shape"] and str(a.dtype) == per_entry["generator_call"]["dtype"]
+        assert list(b.shape) == per_entry["infer_hifigan"]["shape"] and str(b.dtype) == per_entry["infer_hifigan"]["dtype"]
+    # singleton: same path -> same instance; force_reload -> new one
+    first = hp.get_pretrained_hifigan(flat)
+    assert hp.get_pretrained_hifigan(flat) is first and hp.get_pretrained_hifigan(flat, force_reload=True) is not first
+    for key in ("generator", "model", "state_dict"):
+        nested = tmp_path / f"nested_{key}.ckpt"
+        torch.save({key: {k: torch.from_numpy(v) for k, v in sd.items()}}, nested)
+        assert np.array_equal(hp.HiFiGANGenerator(nested)(g["mel"]), out)
+    # HiFiGANModel.forward keeps the reference's tensor contract
+    m = hp.HiFiGANModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    y = m(torch.from_numpy(g["mel"]).cuda())
+    assert y.shape == (2, 1, 4096) and y.is_cuda and np.abs(y.cpu().numpy() - g["wav"]).max() <= TOL_WAV
+
+
+def test_dropin_keras_twin_on_gpu(golden, case_setup):
+    """iris.vocoder: Keras-layout parameters (no weight-norm, [k,C_in,C_out] / [k,C_out,C_in] kernels)
+    loaded from the PyTorch twin's folded weights reproduce the reference's golden waveform; wrapper
+    shape rules of HiFiGANVocoder.infer (vocoder.py:191-207)."""
+    from iris import vocoder
+    from iris._weights import folded_layers, reference_to_keras_layout
+    cfg, sd = case_setup("v1_default_B2_T16")
+    g = golden("v1_default_B2_T16")
+    voc = vocoder.create_vocoder()
+    weights = {}
+    for spec, w, b in folded_layers(cfg, sd):
+        weights[f"{spec.name}.kernel"] = reference_to_keras_layout(spec, w)
+        weights[f"{spec.name}.bias"] = b
+    voc.model.set_weights_dict(weights)
+    out = voc.infer(g["mel"].astype(np.float64))                      # float64 in, like demo_vocoder.py:101
+    assert out.shape == (2, 4096) and out.dtype == np.float32
+    assert np.abs(out - g["wav"][:, 0, :]).max() <= TOL_WAV
+    assert voc(g["mel"][0]).shape == (4096,)                          # [80,T] -> [256T]
+    assert voc.infer(g["mel"][:1]).shape == (1, 4096)                 # batch-1 3-D input stays 2-D
+    y = voc.model(np.transpose(g["mel"], (0, 2, 1)), training=False)  # channels-last model call
+    assert y.shape == (2, 4096, 1)
