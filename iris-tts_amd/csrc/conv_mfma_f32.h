@@ -67,6 +67,9 @@ struct ConvLaunch {
     int in_act;
     int x_channels_first;
     float slope;
+    float* sum_y;        // MRF kernel only: when set, the launch is the last conv step of a stage and stores
+                         // mean_j(branch output j) here instead of the per-branch outputs
+    float sum_div;       // num_kernels as float
     unsigned long long* dbg;  // diagnostics only (stamp builds): 7 accumulators, else nullptr
     int ablate;          // diagnostics only (env IRIS_HIFIGAN_ABLATE): 1 skip staging, 2 weights from one
                          // address, 4 skip epilogue stores, 8 skip residual read.  Results are wrong.

@@ -407,6 +407,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     }
 
     int L = T;
+    bool prev_summed = false;   // the previous stage left mean(branches) in y[0] (MRF kernel's summing step)
     for (size_t i = 0; i < h->stages.size(); ++i) {
         const Stage& st = h->stages[i];
         const int L_out = L * st.rate;
@@ -418,10 +419,13 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
             a.p[0].wp = (const f32x4*)(blob + l.w_off); a.p[0].bias = blob + l.b_off;
             a.p[0].res = nullptr; a.p[0].y = ws + w.up;
             a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
-            int n_in = 1;
+            // bytes are reported in accounting L (the MRF accumulation costs one extra read
+            // per additional branch) whether or not the summing step already folded the mean
+            const int n_in = i == 0 ? 1 : nk;
             if (i == 0) { a.p[0].x = ws + w.pre; a.in_act = IN_ACT_LRELU; }
+            else if (prev_summed) { a.p[0].x = ws + w.y[0]; a.in_act = IN_ACT_LRELU; }
             else {
-                a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk; n_in = nk;
+                a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk;
                 for (int j = 0; j < nk; ++j) a.xmrf[j] = ws + w.y[j];
                 a.p[0].x = a.xmrf[0];
             }
@@ -461,9 +465,26 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 static const int stop_after = [] { const char* e = getenv("IRIS_HIFIGAN_STOP_AFTER_MRF"); return e ? atoi(e) : -1; }();
                 if (stop_after >= 0 && (int)i * 100 + 2 * m + half > stop_after) { h->n_rec = prof.idx; return IRIS_HIFIGAN_OK; }   // debugging aid
                 static const int use_mrf = [] { const char* e = getenv("IRIS_HIFIGAN_MRF"); return e ? atoi(e) : 1; }();
-                static const int mrf_stage_mask = [] { const char* e = getenv("IRIS_HIFIGAN_MRF_STAGES"); return e ? atoi(e) : 0xff; }();
-                if (use_mrf && ((mrf_stage_mask >> i) & 1) && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
-                else                                         HIP_TRY(launch_conv(a, nk, stream));
+                static const int use_sum = [] { const char* e = getenv("IRIS_HIFIGAN_MRFSUM"); return e ? atoi(e) : 1; }();
+                bool launched = false;
+                if (use_mrf && use_sum && m == nd - 1 && half == 1 && nk == 3) {
+                    // last step of the stage: the MRF kernel can form mean_j(y_j) itself.  It processes
+                    // p[2], p[1], p[0]; passing the branches reversed makes that resblock 0, 1, 2 -- the
+                    // reference's summation order (hifigan_pretrained.py:131-137).  The mean goes to y[0]
+                    // (in place: each lane overwrites only elements it read itself as branch 0's residual).
+                    ConvLaunch b = a;
+                    b.p[0] = a.p[2]; b.p[2] = a.p[0];
+                    b.sum_y = ws + w.y[0]; b.sum_div = (float)nk;
+                    if (mrf_kernel_applicable(b, nk)) {
+                        HIP_TRY(launch_mrf_conv(b, nk, stream));
+                        launched = true; prev_summed = true;
+                    }
+                }
+                if (!launched) {
+                    if (m == nd - 1 && half == 1) prev_summed = false;
+                    if (use_mrf && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
+                    else                                         HIP_TRY(launch_conv(a, nk, stream));
+                }
                 TRY(prof.end());
             }
         }
@@ -474,8 +495,9 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     {
         ConvPostLaunch a; memset(&a, 0, sizeof(a));
         const ConvLayer& l = h->post;
-        for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
-        a.n_in = nk; a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
+        if (prev_summed) { a.x[0] = ws + w.y[0]; a.n_in = 1; }
+        else { for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j]; a.n_in = nk; }
+        a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
         a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope;
         TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
                        4.0 * (fB * L * l.C_in * nk + fB * L + (double)l.ref_w_floats + 1)));

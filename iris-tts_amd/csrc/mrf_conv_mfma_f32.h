@@ -61,7 +61,7 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc,
 }
 constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
 
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC>
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM>
 __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = CIC + 4;
@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #define IRIS_SEG(i, a_, b_)
 #endif
     f32x16 acc[MT];
+    f32x16 sumv[MT];      // SUM kernels only: running MRF sum of the branch outputs of this tile
     f32x4 bw[DB + 1];     // ring of weight fragments; groups 0..DB-1 of a phase are requested by the
                           // phase before it (or by the prologue)
 
@@ -304,14 +305,33 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[m][4 * g + e] = (acc[m][4 * g + e] + bias4[g][e]) + resv[m * 4 + g][e];
+                if constexpr (SUM) {
+                    // Last conv step of the stage: the block has all branch outputs of its tile, so the MRF
+                    // sum and the division by num_kernels (hifigan_pretrained.py:131-137) happen here, in
+                    // the reference's order -- the host passes the branches reversed, so the first branch
+                    // processed (PI == 2) is resblock 0: xs = rb0; xs += rb1; xs += rb2; x = xs / 3.
+                    // Only the mean is stored (into a.sum_y); the per-branch outputs are never written.
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if constexpr (PI == 2) sumv[m][r] = acc[m][r];
+                            else                   sumv[m][r] = sumv[m][r] + acc[m][r];
+                            if constexpr (PI == 0) sumv[m][r] = sumv[m][r] / a.sum_div;
+                        }
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!SUM || PI == 0) {
+                    const __amdgpu_buffer_rsrc_t yo = SUM ? make_rsrc(a.sum_y + t.batch_off, tensor_bytes) : yr;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
+                    for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-                        if (!(ablate & 4) || v.x == 1.2345e-30f)
-                            buf_store4(v, yr, t.ovoff4, (unsigned)(m * 32 * C + 8 * g) * 4u);
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x16& src = SUM ? sumv[m] : acc[m];
+                            const f32x4 v = {src[4 * g + 0], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+                            if (!(ablate & 4) || v.x == 1.2345e-30f)
+                                buf_store4(v, yo, t.ovoff4, (unsigned)(m * 32 * C + 8 * g) * 4u);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -376,7 +396,10 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
     if (a.C_in != a.C_out || (a.C_in & 3) || a.L_in != a.L_out || a.out_stride != 1 || a.out_off != 0) return false;
     if (a.n_idx != a.L_out) return false;
     if ((uint64_t)a.L_in * a.C_in * 4u >= 0x7fffffffull) return false;       // 32-bit buffer offsets
-    if (nz != 3 || a.p[0].ks != 3 || a.p[1].ks != 7 || a.p[2].ks != 11) return false;   // the V1 MRF
+    if (nz != 3) return false;
+    const bool fwd = a.p[0].ks == 3 && a.p[1].ks == 7 && a.p[2].ks == 11;     // the V1 MRF
+    const bool rev = a.p[0].ks == 11 && a.p[1].ks == 7 && a.p[2].ks == 3;     // ... reversed, for the summing step
+    if (a.sum_y ? !rev : !fwd) return false;
     if (a.in_act != IN_ACT_LRELU || !(a.slope >= 0.f && a.slope <= 1.f)) return false;
     for (int j = 0; j < nz; ++j) {
         if (packed_conv1d_floats(a.C_in, a.C_out, a.p[j].ks) * 4u >= 0x7fffffffull) return false;
@@ -396,7 +419,6 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     a.nz_serial = nz;
     a.nz = 1;
     static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
-    static const int db_env = [] { const char* e = getenv("IRIS_HIFIGAN_DB"); return e ? atoi(e) : 4; }();
     a.ablate = ablate_env;
     const size_t lds_bytes = (size_t)(t.T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
     const int n_t = (a.L_out + t.T_BLK - 1) / t.T_BLK;
@@ -413,9 +435,9 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const long long rounds = (n_tiles + g - 1) / g;
     g = (n_tiles + rounds - 1) / rounds;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
-#define IRIS_MRF_LAUNCH(WT_, WC_, CIC_, DB_)                                                     \
+#define IRIS_MRF_LAUNCH_K(kfn_)                                                                  \
     do {                                                                                          \
-        auto kfn = mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, DB_, 3, 7, 11>;                              \
+        auto kfn = kfn_;                                                                          \
         if (lds_bytes > 64 * 1024) {                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
@@ -425,7 +447,10 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
     } while (0)
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
-    do { if (db_env >= 6) IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 6); else IRIS_MRF_LAUNCH(WT_, WC_, CIC_, 4); } while (0)
+    do {                                                                                          \
+        if (a.sum_y) IRIS_MRF_LAUNCH_K((mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true>));   \
+        else         IRIS_MRF_LAUNCH_K((mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false>));  \
+    } while (0)
 #ifdef IRIS_MRF_STAMPS
     static unsigned long long* dbg_dev = nullptr;
     if (!dbg_dev) { if (hipMalloc(&dbg_dev, 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
@@ -451,7 +476,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB
-#undef IRIS_MRF_LAUNCH
+#undef IRIS_MRF_LAUNCH_K
     return hipGetLastError();
 }
 
