@@ -194,7 +194,7 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bw[e], acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[e], av[m][e], acc[m], 0, 0, 0);
             };
             auto load_a = [&](f32x4 (&av)[MT], int n) {
                 const float* ap = a_ptr(n);
@@ -237,21 +237,66 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
     }
 
     if (!wave_active) return;
-    // Epilogue. D layout of the 32x32 tile: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const int co = ct * 32 + lo;
-    if (co >= a.C_out) return;
-    const float bias = p.bias[co];
+    // Epilogue.  The MFMA is issued as D = W_frag x X_frag^T, i.e. D[co][t]: lane = time step
+    // (col = lane & 31), registers 4g..4g+3 = the 4 consecutive channels ct*32 + 8g + 4*(lane>>5) + {0..3}:
+    // one 16-byte piece of a channels-last row.
+    const int i = i0 + wt * MT * 32 + lo;                    // row index of (m = 0); m adds 32
+    if ((a.C_out & 3) == 0) {
+        // 16-byte path.  Bias/residual are added in place and every store reads registers that are not
+        // rewritten afterwards: hipcc re-uses a dwordx4 store's data VGPRs two instructions later, which
+        // was observed to corrupt stores under load (see mrf_conv_mfma_f32.h).
+        size_t offs[MT];
+        bool ok[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MT; ++m) {
+            const int im = i + m * 32;
+            const int o = im * a.out_stride + out_off;
+            ok[m] = im < a.n_idx && o >= 0 && o < a.L_out;
+            offs[m] = ((size_t)b * a.L_out + (ok[m] ? o : 0)) * a.C_out + ct * 32 + 4 * hi;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + wt * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int o = i * a.out_stride + out_off;
-            if (i < a.n_idx && o >= 0 && o < a.L_out) {
-                const size_t off = ((size_t)b * a.L_out + o) * a.C_out + co;
-                float v = acc[m][r] + bias;
-                if (p.res && !(a.ablate & 8)) v += p.res[off];
-                if (!(a.ablate & 4) || v == 1.2345e-30f) p.y[off] = v;
+        for (int g = 0; g < 4; ++g) {
+            const int co = ct * 32 + 8 * g + 4 * hi;
+            if (co < a.C_out) {
+                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+                    if (p.res && ok[m] && !(a.ablate & 8)) r4 = *reinterpret_cast<const f32x4*>(p.res + offs[m] + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[m][4 * g + e] = (acc[m][4 * g + e] + bias4[e]) + r4[e];
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = ct * 32 + 8 * g + 4 * hi;
+                if (ok[m] && co < a.C_out && !(a.ablate & 4)) {
+                    const f32x4 v = {acc[m][4 * g + 0], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(p.y + offs[m] + 8 * g) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // scalar path for channel counts that are not a multiple of 4
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int im = i + m * 32;
+            const int o = im * a.out_stride + out_off;
+            if (!(im < a.n_idx && o >= 0 && o < a.L_out)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < a.C_out) {
+                    const size_t off = ((size_t)b * a.L_out + o) * a.C_out + co;
+                    float v = acc[m][r] + p.bias[co];
+                    if (p.res && !(a.ablate & 8)) v += p.res[off];
+                    if (!(a.ablate & 4)) p.y[off] = v;
+                }
             }
         }
     }
