@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
+                    "gloo only for rehearsing the control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,11 +108,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the vocoder path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.backend == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} HIP device(s): RCCL needs one GPU per rank")
+    dev = torch.device("cuda", local_rank % n_dev)     # (ranks share a GPU only in a gloo rehearsal)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     cfg = GeneratorConfig()
     sd = seeded_state_dict(cfg, seed=2024)                       # random-init weights of the V1 architecture
@@ -196,7 +204,9 @@ def main():
                                f"each, fp32" + (" (BASELINE.json configs[1])" if (B, T) == (1, 1000) else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "frames": T, "hop_length": eng.hop_length,
                    "weights": "random-init (seeded) V1 architecture, 13,926,017 values",
-                   "sharding": "batch items across ranks, RCCL all-gather of waveforms" if world > 1 else "single GPU",
+                   "sharding": (f"batch items across ranks, all-gather of waveforms over {args.backend}"
+                                + (" (RCCL)" if args.backend == "nccl" else " (control-flow rehearsal, not a measurement)"))
+                               if world > 1 else "single GPU",
                    "launch_events_in_timed_region": profile},
         "rtf": (ms_per_step * 1e-3) / (T * eng.hop_length / SAMPLE_RATE) if B == 1 else None,
         "flop_per_step": work["flop_per_frame"] * B * T * world,
