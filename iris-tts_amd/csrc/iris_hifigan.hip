@@ -475,7 +475,8 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                     ConvLaunch b = a;
                     b.p[0] = a.p[2]; b.p[2] = a.p[0];
                     b.sum_y = ws + w.y[0]; b.sum_div = (float)nk;
-                    if (mrf_kernel_applicable(b, nk)) {
+                    // (small problems run one branch per block -- mrf_plan's latency mode -- and cannot sum)
+                    if (mrf_kernel_applicable(b, nk) && !mrf_plan(b, true).zpar) {
                         HIP_TRY(launch_mrf_conv(b, nk, stream));
                         launched = true; prev_summed = true;
                     }

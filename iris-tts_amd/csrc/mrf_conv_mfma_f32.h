@@ -61,7 +61,7 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc,
 }
 constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
 
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM>
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, bool ZPAR>
 __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = CIC + 4;
@@ -350,11 +350,14 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    Tile t = make_tile(tile);
-    {   // prologue: the first window and the first weight fragments (the only latencies a block exposes)
-        const ConvProblem& p0 = a.p[2];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // prologue: the first window and the first weight fragments of problem PI (the only latencies a
+    // block exposes)
+    auto prologue = [&](auto pi_tag, const Tile& t) {
+        constexpr int PI = decltype(pi_tag)::value;
+        const ConvProblem& p0 = a.p[PI];
         const int R0 = T_BLK + (p0.ks - 1) * p0.dil;
         const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p0.x + t.batch_off, tensor_bytes);
         const __amdgpu_buffer_rsrc_t wr0 = make_rsrc(p0.wp, (unsigned)(p0.ks * a.Gp) * wbytes_group);
@@ -365,21 +368,49 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         for (int d = 0; d < DB; ++d) bw[d] = buf_load4(wr0, t.wvoff, (unsigned)d * wbytes_group);
         stage_write_all(R0);
         __syncthreads();
-    }
-    // persistent over tiles; branches heaviest first: p[2] (KC taps), p[1] (KB), p[0] (KA)
-    for (;;) {
-        const int tile_next = tile + (int)gridDim.x;
-        const bool more = tile_next < n_tiles;
-        const Tile tn = make_tile(more ? tile_next : tile);
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
-        run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
-        run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
-        if (!more) break;
-        tile = tile_next;
-        t = tn;
+    };
+    if constexpr (!ZPAR) {
+        // equal-cost blocks: every block runs all three branches of its tiles, heaviest first:
+        // p[2] (KC taps), p[1] (KB), p[0] (KA); persistent over tiles
+        int tile = blockIdx.x;
+        if (tile >= n_tiles) return;
+        Tile t = make_tile(tile);
+        prologue(I2{}, t);
+        for (;;) {
+            const int tile_next = tile + (int)gridDim.x;
+            const bool more = tile_next < n_tiles;
+            const Tile tn = make_tile(more ? tile_next : tile);
+            run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
+            run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
+            run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
+            if (!more) break;
+            tile = tile_next;
+            t = tn;
+        }
+    } else {
+        // latency mode for small problems (fewer tiles than CUs): one branch per block, so a stage
+        // step is spread over 3x the blocks.  gridDim.x is a multiple of 3; block b serves branch
+        // 2 - b%3 (heaviest first in dispatch order) for tiles b/3, b/3 + gridDim.x/3, ...
+        const int zb = 2 - (int)(blockIdx.x % 3u);
+        const int step = (int)(gridDim.x / 3u);
+        int tile = (int)(blockIdx.x / 3u);
+        if (tile >= n_tiles) return;
+        Tile t = make_tile(tile);
+        auto walk = [&](auto ks_tag, auto pi_tag) {
+            prologue(pi_tag, t);
+            for (;;) {
+                const int tile_next = tile + step;
+                const bool more = tile_next < n_tiles;
+                const Tile tn = make_tile(more ? tile_next : tile);
+                run_branch(ks_tag, pi_tag, pi_tag, t, more, tn);
+                if (!more) break;
+                tile = tile_next;
+                t = tn;
+            }
+        };
+        if (zb == 2)      walk(std::integral_constant<int, KC>{}, I2{});
+        else if (zb == 1) walk(std::integral_constant<int, KB>{}, I1{});
+        else              walk(std::integral_constant<int, KA>{}, I0{});
     }
 #ifdef IRIS_MRF_STAMPS
     seg[5] = stamp() - t_entry;
@@ -401,6 +432,7 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
     const bool rev = a.p[0].ks == 11 && a.p[1].ks == 7 && a.p[2].ks == 3;     // ... reversed, for the summing step
     if (a.sum_y ? !rev : !fwd) return false;
     if (a.in_act != IN_ACT_LRELU || !(a.slope >= 0.f && a.slope <= 1.f)) return false;
+    { const ConvTile tt = pick_tile(a.C_in, a.C_out); if (tt.WT == 4 && tt.CIC != 32) return false; }
     for (int j = 0; j < nz; ++j) {
         if (packed_conv1d_floats(a.C_in, a.C_out, a.p[j].ks) * 4u >= 0x7fffffffull) return false;
         const int ks = a.p[j].ks;
@@ -408,6 +440,45 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
         if ((ks - 1) * a.p[j].dil > kMrfSpanMax) return false;
     }
     return true;
+}
+
+// How a grouped MRF step is spread over the chip.
+struct MrfPlan { int MT; bool zpar; long long n_tiles; long long grid; };
+
+inline int mrf_cu_count() {
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    return n_cu;
+}
+
+// Persistent grid of at most `per_cu` blocks per CU, evened out so that every block walks the same
+// number of tiles (+-1): 1000 tiles on 256 CUs x 2 -> 2 rounds -> 500 blocks of 2 tiles.
+// Small problems: with fewer than 2 tiles per CU the tile height is halved (MT = 1); if that still
+// leaves CUs without a block, every branch gets its own blocks (zpar, 3x the blocks, unequal cost).
+inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar) {
+    static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
+    static const int plan_env = [] { const char* e = getenv("IRIS_HIFIGAN_MRFPLAN"); return e ? atoi(e) : -1; }();  // diagnostics: 0 MT2, 1 MT1, 2 MT1+zpar
+    const ConvTile t = pick_tile(a.C_in, a.C_out);
+    const int n_cu = mrf_cu_count();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
+    const int n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
+    auto tiles = [&](int MT) { return (long long)((a.L_out + t.WT * MT * 32 - 1) / (t.WT * MT * 32)) * n_co_blk * a.B; };
+    MrfPlan pl;
+    pl.MT = 2; pl.zpar = false;
+    if (plan_env >= 0) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar; }
+    else if (4 * tiles(2) < 3LL * n_cu * per_cu) {          // fewer than ~1.5 tiles per CU
+        pl.MT = 1;
+        pl.zpar = allow_zpar && tiles(1) < n_cu;
+    }
+    pl.n_tiles = tiles(pl.MT);
+    long long cap = (long long)n_cu * per_cu;
+    if (pl.zpar) cap = cap / 3 > 0 ? cap / 3 : 1;
+    long long g = pl.n_tiles < cap ? pl.n_tiles : cap;
+    if (g < 1) g = 1;
+    const long long rounds = (pl.n_tiles + g - 1) / g;
+    g = (pl.n_tiles + rounds - 1) / rounds;
+    pl.grid = pl.zpar ? 3 * g : g;
+    return pl;
 }
 
 inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
@@ -420,24 +491,15 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     a.nz = 1;
     static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate_env;
-    const size_t lds_bytes = (size_t)(t.T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
-    const int n_t = (a.L_out + t.T_BLK - 1) / t.T_BLK;
-    const long long n_tiles = (long long)n_t * a.n_co_blk * a.B;
-    if (n_tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    // Persistent grid: at most `per_cu` blocks per CU, then evened out so that every block walks the
-    // same number of tiles (+-1): 1000 tiles on 256 CUs x 3 -> 2 rounds -> 500 blocks of 2 tiles.
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
-                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
-    const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;   // blocks (of 4 waves) per CU
-    long long g = (long long)n_cu * per_cu;
-    if (g > n_tiles) g = n_tiles;
-    const long long rounds = (n_tiles + g - 1) / g;
-    g = (n_tiles + rounds - 1) / rounds;
+    const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr);
+    const int T_BLK = t.WT * pl.MT * 32;
+    const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
+    const long long n_tiles = pl.n_tiles, g = pl.grid;
+    if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
-#define IRIS_MRF_LAUNCH_K(kfn_)                                                                  \
+#define IRIS_MRF_LAUNCH_K(...)                                                                    \
     do {                                                                                          \
-        auto kfn = kfn_;                                                                          \
+        auto kfn = __VA_ARGS__;                                                                   \
         if (lds_bytes > 64 * 1024) {                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
@@ -448,8 +510,12 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     } while (0)
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
     do {                                                                                          \
-        if (a.sum_y) IRIS_MRF_LAUNCH_K((mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true>));   \
-        else         IRIS_MRF_LAUNCH_K((mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false>));  \
+        if (pl.MT == 2) {                                                                         \
+            if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true, false>);   \
+            else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, false>);  \
+        } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 11, 7, 3, true, false>);   \
+        else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, true>);   \
+        else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, false>);  \
     } while (0)
 #ifdef IRIS_MRF_STAMPS
     static unsigned long long* dbg_dev = nullptr;
@@ -457,10 +523,9 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     (void)hipMemsetAsync(dbg_dev, 0, 8 * sizeof(unsigned long long), stream);
     a.dbg = dbg_dev;
 #endif
-    if (t.WT == 4 && t.CIC == 32)      IRIS_MRF_LAUNCH_DB(4, 1, 32);
-    else if (t.WT == 4)                IRIS_MRF_LAUNCH_DB(4, 1, 64);
-    else if (t.WT == 2)                IRIS_MRF_LAUNCH_DB(2, 2, 64);
-    else                               IRIS_MRF_LAUNCH_DB(1, 4, 64);
+    if (t.WT == 4)          IRIS_MRF_LAUNCH_DB(4, 1, 32);     // C <= 32 (mrf_kernel_applicable: CIC == 32 there)
+    else if (t.WT == 2)     IRIS_MRF_LAUNCH_DB(2, 2, 64);
+    else                    IRIS_MRF_LAUNCH_DB(1, 4, 64);
 #ifdef IRIS_MRF_STAMPS
     {   // diagnostic build: synchronous read-back of the per-wave cycle shares
         unsigned long long h[8];
