@@ -141,6 +141,21 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
                                   int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
                                   void* stream);
 
+/* ---- PostNet, the layer in front of the vocoder --------------------------
+ * Replaces `postnet(mel_bt_f, training=False)` (scripts/synthesize.py:148-166; model src/iris/postnet.py:48-67):
+ * num_layers Conv1D(kernel_size, 'same') layers over time, the first num_layers-1 with `channels`
+ * filters + BatchNorm + tanh, the last back to n_mels + BatchNorm; output = mel + residual.
+ * `weights_host`: per layer, weight [C_out, C_in, k] then bias [C_out], with the inference BatchNorm
+ * already folded in (w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta).                     */
+typedef struct iris_postnet_handle iris_postnet_handle;
+int32_t iris_postnet_create(int32_t n_mels, int32_t num_layers, int32_t channels, int32_t kernel_size,
+                            const float* weights_host, uint64_t n_weights, iris_postnet_handle** out);
+int32_t iris_postnet_destroy(iris_postnet_handle* h);
+int32_t iris_postnet_workspace_bytes(const iris_postnet_handle* h, int32_t B, int32_t T, uint64_t* bytes);
+/* mel_dev, out_dev: [B, n_mels, T] fp32 (channels-first, like the reference); asynchronous on `stream`. */
+int32_t iris_postnet_forward(iris_postnet_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                             void* out_dev, void* workspace_dev, uint64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,7 @@ struct ConvLaunch {
     int in_act;
     int x_channels_first;
     float slope;
+    int out_act;         // 0 none, 1 tanh applied to (acc + bias) before the residual is added (PostNet)
     float* sum_y;        // MRF kernel only: when set, the launch is the last conv step of a stage and stores
                          // mean_j(branch output j) here instead of the per-branch outputs
     float sum_div;       // num_kernels as float
@@ -264,7 +265,11 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
                     f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
                     if (p.res && ok[m] && !(a.ablate & 8)) r4 = *reinterpret_cast<const f32x4*>(p.res + offs[m] + 8 * g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[m][4 * g + e] = (acc[m][4 * g + e] + bias4[e]) + r4[e];
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[m][4 * g + e] + bias4[e];
+                        if (a.out_act == 1) v = tanhf(v);
+                        acc[m][4 * g + e] = v + r4[e];
+                    }
                 }
             }
         }
@@ -294,6 +299,7 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
                 if (co < a.C_out) {
                     const size_t off = ((size_t)b * a.L_out + o) * a.C_out + co;
                     float v = acc[m][r] + p.bias[co];
+                    if (a.out_act == 1) v = tanhf(v);
                     if (p.res && !(a.ablate & 8)) v += p.res[off];
                     if (!(a.ablate & 4)) p.y[off] = v;
                 }

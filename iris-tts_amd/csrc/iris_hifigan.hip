@@ -26,6 +26,7 @@
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
 #include "conv_post.h"
+#include "postnet.h"
 
 using namespace iris;
 
@@ -599,6 +600,123 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
     a.B = B; a.L = L; a.C = C_in; a.k = k; a.slope = slope;
     HIP_TRY(launch_conv_post(a, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PostNet (src/iris/postnet.py:48-67)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct iris_postnet_handle {
+    int n_mels = 0, num_layers = 0, channels = 0, k = 0;
+    std::vector<ConvLayer> layers;
+    float* blob = nullptr;
+    size_t blob_floats = 0;
+};
+
+extern "C" {
+
+int32_t iris_postnet_create(int32_t n_mels, int32_t num_layers, int32_t channels, int32_t kernel_size,
+                            const float* weights_host, uint64_t n_weights, iris_postnet_handle** out) {
+    if (!weights_host || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (n_mels < 1 || channels < 1 || num_layers < 2 || num_layers > 64 || kernel_size < 1 || !(kernel_size & 1))
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "PostNet needs n_mels, channels >= 1, 2 <= num_layers <= 64, odd kernel_size");
+    iris_postnet_handle* h = new (std::nothrow) iris_postnet_handle;
+    if (!h) return fail(IRIS_HIFIGAN_OUT_OF_MEMORY, "host allocation failed");
+    h->n_mels = n_mels; h->num_layers = num_layers; h->channels = channels; h->k = kernel_size;
+    uint64_t expect = 0;
+    size_t off = 0;
+    for (int i = 0; i < num_layers; ++i) {
+        ConvLayer l;
+        l.C_in = i == 0 ? n_mels : channels;
+        l.C_out = i == num_layers - 1 ? n_mels : channels;
+        l.k = kernel_size;
+        l.ref_w_floats = (size_t)l.C_in * l.C_out * l.k;
+        l.w_floats = packed_conv1d_floats(l.C_in, l.C_out, l.k);
+        l.w_off = off; off += (l.w_floats + 3) & ~(size_t)3;
+        l.b_off = off; off += ((size_t)l.C_out + 3) & ~(size_t)3;
+        expect += l.ref_w_floats + l.C_out;
+        h->layers.push_back(l);
+    }
+    h->blob_floats = off;
+    if (n_weights != expect) {
+        delete h;
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "weight blob has %llu values, PostNet needs %llu",
+                    (unsigned long long)n_weights, (unsigned long long)expect);
+    }
+    std::vector<float> host(h->blob_floats, 0.f);
+    const float* src = weights_host;
+    for (const ConvLayer& l : h->layers) {
+        pack_conv1d_weights(src, l.C_in, l.C_out, l.k, host.data() + l.w_off);
+        src += l.ref_w_floats;
+        memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
+        src += l.C_out;
+    }
+    hipError_t e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->blob) (void)hipFree(h->blob);
+        delete h;
+        return fail(IRIS_HIFIGAN_HIP_ERROR, "PostNet weight upload failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_postnet_destroy(iris_postnet_handle* h) {
+    if (!h) return IRIS_HIFIGAN_OK;
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+    return IRIS_HIFIGAN_OK;
+}
+
+// workspace: two ping-pong hidden buffers [B, T, channels] and the residual [B, T, n_mels]
+int32_t iris_postnet_workspace_bytes(const iris_postnet_handle* h, int32_t B, int32_t T, uint64_t* bytes) {
+    if (!h || !bytes) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    const size_t frames = (size_t)B * T;
+    const size_t hid = (frames * h->channels + 63) & ~(size_t)63, res = (frames * h->n_mels + 63) & ~(size_t)63;
+    *bytes = (2 * hid + res) * sizeof(float);
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_postnet_forward(iris_postnet_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                             void* out_dev, void* workspace_dev, uint64_t workspace_bytes, void* stream_) {
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;
+    if (!mel_dev || !out_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
+    if (B > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "batch %d exceeds 65535 (grid.y)", B);
+    uint64_t need = 0;
+    TRY(iris_postnet_workspace_bytes(h, B, T, &need));
+    if (workspace_bytes < need)
+        return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
+                    (unsigned long long)workspace_bytes, (unsigned long long)need);
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t frames = (size_t)B * T;
+    const size_t hid = (frames * h->channels + 63) & ~(size_t)63;
+    float* ws = (float*)workspace_dev;
+    float* hbuf[2] = {ws, ws + hid};
+    float* res = ws + 2 * hid;
+    const float* x = (const float*)mel_dev;
+    for (int i = 0; i < h->num_layers; ++i) {
+        const ConvLayer& l = h->layers[i];
+        const bool last = i == h->num_layers - 1;
+        ConvLaunch a; init_launch(a);
+        a.p[0].x = x; a.p[0].wp = (const f32x4*)(h->blob + l.w_off); a.p[0].bias = h->blob + l.b_off;
+        a.p[0].res = nullptr; a.p[0].y = last ? res : hbuf[i & 1];
+        a.p[0].ks = l.k; a.p[0].dil = 1; a.p[0].pad_left = (l.k - 1) / 2;
+        a.B = B; a.L_in = T; a.L_out = T; a.C_in = l.C_in; a.C_out = l.C_out; a.n_idx = T;
+        a.in_act = IN_ACT_NONE; a.x_channels_first = i == 0 ? 1 : 0;   // the mel arrives [B, n_mels, T]
+        a.out_act = last ? 0 : 1;                                       // tanh (postnet.py:59)
+        HIP_TRY(launch_conv(a, 1, stream));
+        x = a.p[0].y;
+    }
+    dim3 grid((unsigned)((T + 255) / 256), (unsigned)B), block(256);
+    hipLaunchKernelGGL(postnet_residual_kernel, grid, block, 0, stream, (const float*)mel_dev, (const float*)res,
+                       (float*)out_dev, h->n_mels, T);                  // x + res (postnet.py:67)
+    HIP_TRY(hipGetLastError());
     return IRIS_HIFIGAN_OK;
 }
 

@@ -180,7 +180,8 @@ def test_keras_twin_construction_and_weight_files(tmp_path):
 # ---- C-ABI ------------------------------------------------------------------------------------
 def test_cabi_exports_every_declared_symbol():
     header = (REPO / "include" / "iris_hifigan.h").read_text()
-    declared = set(re.findall(r"\b(iris_hifigan_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(iris_(?:hifigan|postnet)_[a-z0-9_]+)\s*\(", header))
+    assert {"iris_postnet_create", "iris_postnet_forward", "iris_hifigan_forward"} <= declared
     assert declared == set(_native.SYMBOLS), declared ^ set(_native.SYMBOLS)
     lib = _native.load()
     for name in declared:
