@@ -434,20 +434,28 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
         const int s = (a.p[j].ks - 1) * a.p[j].dil;
         if (s > span) span = s;
     }
-    const size_t lds_bytes = (size_t)(t.T_BLK + span) * (t.CIC + 4) * sizeof(float);
-    const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
     static const int serial_env = [] { const char* e = getenv("IRIS_HIFIGAN_ZSERIAL"); return e ? atoi(e) : 1; }();
     a.z_serial = (!a.z_is_phase && nz > 1 && serial_env) ? serial_env : 0;
     a.nz_serial = nz;
     if (a.z_serial) nz = 1;
     a.nz = nz;
+    // Small grids (conv_pre, the first upsamplers, short utterances): a launch costs one tile's serial
+    // time, so when the grid cannot give every CU two blocks the tile height is halved (MT = 1).
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int mt_env = [] { const char* e = getenv("IRIS_HIFIGAN_CONV_MT"); return e ? atoi(e) : 0; }();
+    const long long blocks2 = (long long)((a.n_idx + t.T_BLK - 1) / t.T_BLK) * a.n_co_blk * nz * a.B;
+    const int MT = mt_env ? mt_env : (blocks2 < 2LL * n_cu ? 1 : 2);
+    const int T_BLK = t.WT * MT * 32;
+    const size_t lds_bytes = (size_t)(T_BLK + span) * (t.CIC + 4) * sizeof(float);
+    const int n_t = (a.n_idx + T_BLK - 1) / T_BLK;
     static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate_env;
     dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-#define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
+#define IRIS_LAUNCH_K(...)                                                                        \
     do {                                                                                          \
-        auto kfn = conv_mfma_f32_kernel<WT_, WC_, 2, CIC_>;                                       \
+        auto kfn = __VA_ARGS__;                                                                   \
         if (lds_bytes > 64 * 1024) {                                                              \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
@@ -456,10 +464,14 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
         }                                                                                         \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
     } while (0)
+#define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
+    do { if (MT == 1) IRIS_LAUNCH_K(conv_mfma_f32_kernel<WT_, WC_, 1, CIC_>);                     \
+         else         IRIS_LAUNCH_K(conv_mfma_f32_kernel<WT_, WC_, 2, CIC_>); } while (0)
     if (t.WT == 4 && t.CIC == 32)      IRIS_LAUNCH(4, 1, 32);
     else if (t.WT == 4)                IRIS_LAUNCH(4, 1, 64);
     else if (t.WT == 2)                IRIS_LAUNCH(2, 2, 64);
     else                               IRIS_LAUNCH(1, 4, 64);
+#undef IRIS_LAUNCH_K
 #undef IRIS_LAUNCH
     return hipGetLastError();
 }
