@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
+                    "roofline is then null; the default eager mode is the measured configuration)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
                     "gloo only for rehearsing the control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -130,9 +132,12 @@ def main():
     gathered = torch.empty((B * world, T * eng.hop_length), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
-        eng.forward(mel, out=wav)
+        if args.graph:
+            out = eng.forward_graph(mel)
+        else:
+            out = eng.forward(mel, out=wav)
         if world > 1:
-            gather_waveforms(wav, B * world, out=gathered)
+            gather_waveforms(out, B * world, out=gathered)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -142,7 +147,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    profile = not args.no_profile
+    profile = not args.no_profile and not args.graph
     fence()
     eng.set_profiling(profile)
     t0 = time.perf_counter()
@@ -207,7 +212,7 @@ def main():
                    "sharding": (f"batch items across ranks, all-gather of waveforms over {args.backend}"
                                 + (" (RCCL)" if args.backend == "nccl" else " (control-flow rehearsal, not a measurement)"))
                                if world > 1 else "single GPU",
-                   "launch_events_in_timed_region": profile},
+                   "launch_events_in_timed_region": profile, "hipgraph_replay": bool(args.graph)},
         "rtf": (ms_per_step * 1e-3) / (T * eng.hop_length / SAMPLE_RATE) if B == 1 else None,
         "flop_per_step": work["flop_per_frame"] * B * T * world,
         "tflops_whole_path": work["flop_per_frame"] * B * T * world / (ms_per_step * 1e-3) / 1e12,

@@ -49,12 +49,14 @@ class GeneratorEngine:
         _native.check("iris_hifigan_hop_length", self.lib.iris_hifigan_hop_length(self._handle, ctypes.byref(hop)))
         self.hop_length = int(hop.value)
         self._workspace: Optional[torch.Tensor] = None
+        self._graphs: dict = {}
 
     # -- lifetime ----------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:
             self.lib.iris_hifigan_destroy(self._handle)
             self._handle = ctypes.c_void_p()
+        self._graphs = {}
         self._workspace = None
 
     def __del__(self):
@@ -101,6 +103,47 @@ class GeneratorEngine:
         return out
 
     __call__ = forward
+
+    # -- hipGraph replay ---------------------------------------------------------------------------
+    def forward_graph(self, mel: torch.Tensor) -> torch.Tensor:
+        """Same result as ``forward`` but the launches of one forward are captured once per
+        (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 30
+        kernel launches, and the inter-kernel gaps shrink to the graph's own.  ``iris_hifigan_forward`` is
+        capture-safe by construction (no allocation, no synchronisation, caller's stream).  The returned
+        tensor is the graph's static output buffer: it is overwritten by the next replay of the same shape.
+        Per-launch profiling records are not produced in this mode."""
+        if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
+            raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
+        batch, _, frames = mel.shape
+        if batch == 0 or frames == 0:
+            return self.forward(mel)
+        key = (batch, frames)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = torch.empty((batch, self.cfg.in_channels, frames), dtype=torch.float32, device=self.device)
+            static_out = torch.empty((batch, frames * self.hop_length), dtype=torch.float32, device=self.device)
+            self._get_workspace(self.workspace_bytes(batch, frames))     # allocate before capture
+            ws_ptr = self._workspace.data_ptr()
+            static_in.copy_(mel)
+            self.set_profiling(False)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                                # warm-up outside capture
+                self.forward(static_in, out=static_out)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.forward(static_in, out=static_out)
+            entry = (graph, static_in, static_out, ws_ptr)
+            self._graphs[key] = entry
+        graph, static_in, static_out, ws_ptr = entry
+        if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
+            # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
+            del self._graphs[key]
+            return self.forward_graph(mel)
+        static_in.copy_(mel.to(device=self.device, dtype=torch.float32))
+        graph.replay()
+        return static_out
 
     # -- profiling (bench.py roofline leg) -----------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:
