@@ -203,6 +203,8 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const bool last = chunk + 1 == n_chunks;
             const bool has_next = !last || next_valid;
+            f32x4 outv[MT * 4];        // store data of this branch's epilogue (see keep-alive below)
+            bool stored = false;
             // the phase that follows: next chunk of this branch, or chunk 0 of (a.p[PN], tn)
             const bool cross = last && next_valid;
             const float* xq = cross ? a.p[PN].x + tn.batch_off : p.x + t.batch_off;
@@ -328,11 +330,15 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x16& src = SUM ? sumv[m] : acc[m];
-                            const f32x4 v = {src[4 * g + 0], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
-                            if (!(ablate & 4) || v.x == 1.2345e-30f)
-                                buf_store4(v, yo, t.ovoff4, (unsigned)(m * 32 * C + 8 * g) * 4u);
+                            outv[m * 4 + g] = f32x4{src[4 * g + 0], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int idx = 0; idx < MT * 4; ++idx)
+                        if (!(ablate & 4) || outv[idx].x == 1.2345e-30f)
+                            buf_store4(outv[idx], yo, t.ovoff4, (unsigned)((idx / 4) * 32 * C + 8 * (idx % 4)) * 4u);
+                    stored = true;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -343,6 +349,12 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 IRIS_STAMP(ts3);
                 stage_write_all(Rn);
                 IRIS_STAMP(ts4);
+                if (stored) {
+                    // keep the epilogue's store-data registers allocated until here: nothing may be
+                    // written into them right behind the buffer_store_dwordx4s that read them
+#pragma unroll
+                    for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));
+                }
                 __syncthreads();
                 IRIS_STAMP(ts5);
                 IRIS_SEG(2, ts2, ts3); IRIS_SEG(3, ts3, ts4); IRIS_SEG(4, ts4, ts5);
