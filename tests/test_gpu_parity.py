@@ -338,3 +338,23 @@ def test_hipgraph_replay_matches_eager(dev):
             assert torch.equal(eager, replay), (B, T, seed)
     assert eng.forward_graph(torch.empty((0, 80, 5), device=dev)).shape == (0, 1280)
     eng.close()
+
+
+@pytest.mark.parametrize("B,T", [(1, 3000), (300, 3), (7, 129)])
+def test_generator_long_and_wide_shapes(B, T, dev):
+    """A 35-second utterance (L = 768k rows at the last stage, thousands of tiles per launch), a batch
+    of 300 three-frame items (batch index folded into the tile index) and an odd in-between shape."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    mel = seeded_mel(B + T, B, T, log_mel=True)
+    eng = GeneratorEngine(cfg, sd, dev)
+    got = eng.forward(torch.from_numpy(mel).to(dev)).cpu().numpy()
+    folded = orc.to_torch_folded(sd)
+    idx = sorted({0, B // 2, B - 1})
+    want = orc.generator_forward_torch(folded, mel[idx]).numpy()[:, 0, :]
+    assert got.shape == (B, 256 * T)
+    assert np.abs(got[idx] - want).max() <= TOL_WAV
+    assert np.isfinite(got).all() and np.abs(got).max() <= 1.0
+    eng.close()
