@@ -35,6 +35,7 @@ for p in (str(REPO / "iris-tts_amd"), str(REPO)):
 
 SAMPLE_RATE = 22050
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # dense, same table
 PEAK_HBM_GBS = 8000.0          # spec; 6.3 TB/s achievable
 
 
@@ -84,6 +85,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="mels per GPU (default: configs[1], batch 1)")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the parity path and the headline (default); bf16 = bf16 storage + bf16 MFMA "
+                         "(BASELINE.json configs[2] with --batch 32 --frames 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
@@ -133,9 +137,9 @@ def main():
 
     def step():
         if args.graph:
-            out = eng.forward_graph(mel)
+            out = eng.forward_graph(mel, dtype=args.dtype)
         else:
-            out = eng.forward(mel, out=wav)
+            out = eng.forward(mel, out=wav, dtype=args.dtype)
         if world > 1:
             gather_waveforms(out, B * world, out=gathered)
 
@@ -186,13 +190,25 @@ def main():
         dom = by_kind["mrf_resblock_conv"]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        roofline = {"kernel": "mrf_conv_mfma_f32_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
-                    "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": committed_traffic(B, T),
-                    "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
-                    "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
-                    "bytes_per_launch": dom["bytes"] / dom["n"],
-                    "share_of_step": dom["ms"] / args.steps / ms_per_step}
+        if args.dtype == "f32":
+            roofline = {"kernel": "mrf_conv_mfma_f32_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
+                        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": committed_traffic(B, T),
+                        "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
+                        "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
+                        "bytes_per_launch": dom["bytes"] / dom["n"],
+                        "share_of_step": dom["ms"] / args.steps / ms_per_step}
+        else:
+            # bf16: the MRF launches taken together need more HBM time (bytes / 8 TB/s) than MFMA time
+            # (FLOP / 2.5 PFLOP/s) -- 235 FLOP/B against a machine balance of 312 -- so HBM is the binding roof
+            roofline = {"kernel": "conv_mfma_bf16_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
+                        "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "avg_launch_ms": dom["ms"] / dom["n"], "bytes_per_launch": dom["bytes"] / dom["n"],
+                        "flop_per_launch": dom["flops"] / dom["n"],
+                        "mfma_achieved_tflops": achieved, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                        "mfma_frac": achieved / PEAK_BF16_MFMA_TFLOPS,
+                        "share_of_step": dom["ms"] / args.steps / ms_per_step}
 
     if rank != 0:
         if world > 1:
@@ -204,9 +220,11 @@ def main():
         "metric": "audio samples/sec (22.05 kHz) on 80-mel x %d-frame batch" % T,
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"HiFiGAN-V1 generator, batch {B} per GPU x 80-mel x {T} frames -> {T * eng.hop_length} samples "
-                               f"each, fp32" + (" (BASELINE.json configs[1])" if (B, T) == (1, 1000) else ""),
+                               f"each, " + ("fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate")
+                               + (" (BASELINE.json configs[1])" if (B, T, args.dtype) == (1, 1000, "f32") else "")
+                               + (" (BASELINE.json configs[2])" if (B, T, args.dtype) == (32, 500, "bf16") else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "frames": T, "hop_length": eng.hop_length,
                    "weights": "random-init (seeded) V1 architecture, 13,926,017 values",
                    "sharding": (f"batch items across ranks, all-gather of waveforms over {args.backend}"

@@ -48,7 +48,10 @@ typedef enum iris_hifigan_status {
 } iris_hifigan_status;
 
 typedef enum iris_hifigan_dtype {
-    IRIS_HIFIGAN_F32 = 0 /* fp32 storage, fp32 MFMA (exact fmaf chains) */
+    IRIS_HIFIGAN_F32 = 0, /* fp32 storage, fp32 MFMA (exact fmaf chains): the parity path (<= 1e-4 vs reference) */
+    IRIS_HIFIGAN_BF16 = 1 /* bf16 storage of activations and weights, fp32 accumulation (bf16 MFMA); mel in and
+                             waveform out stay fp32.  BASELINE.json configs[2].  The reference has no bf16 path:
+                             its error against the fp32 generator (~1e-2 max-abs) is documented, not pinned. */
 } iris_hifigan_dtype;
 
 /* Generator hyper-parameters: the constructor arguments of HiFiGANModel
@@ -140,6 +143,18 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
                                   const float* w_host, const float* bias_host, float* y_dev,
                                   int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
                                   void* stream);
+
+/* bf16 variants of the two layers above (dtype IRIS_HIFIGAN_BF16): x_dev / res_dev / y_dev are bf16
+ * channels-last [B, L, C] (C_in % 8 == 0, C_out % 4 == 0); host weights are fp32 in the reference layout and are
+ * rounded to bf16 (nearest even); bias stays fp32; accumulation is fp32, one rounding to bf16 at the store.
+ * Same reference layers: hifigan_pretrained.py:50-57,64-71 (Conv1d) and :100-108,127-128 (ConvTranspose1d). */
+int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
+                                    const void* res_dev, void* y_dev, int32_t B, int32_t L, int32_t C_in,
+                                    int32_t C_out, int32_t k, int32_t dilation, int32_t in_act, float slope,
+                                    void* stream);
+int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
+                                              void* y_dev, int32_t B, int32_t L, int32_t C_in, int32_t C_out,
+                                              int32_t k, int32_t u, int32_t in_act, float slope, void* stream);
 
 /* ---- PostNet, the layer in front of the vocoder --------------------------
  * Replaces `postnet(mel_bt_f, training=False)` (scripts/synthesize.py:148-166; model src/iris/postnet.py:48-67):

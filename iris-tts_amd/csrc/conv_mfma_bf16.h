@@ -1,0 +1,521 @@
+// conv_mfma_bf16.h -- bf16-storage variant of the generator's Conv1d / ConvTranspose1d kernel (gfx950).
+//
+// Same layers and dataflow as conv_mfma_f32.h (reference: HiFiGANModel.forward,
+// src/iris/hifigan_pretrained.py:123-143; ResBlock :64-71), for BASELINE.json configs[2]
+// ("batch=32, 80x500-frame mels, bf16"):
+//   * activations live in HBM as bf16, channels-last [B, L, C]: half the bytes of the fp32 path;
+//   * weights are bf16 (rounded to nearest-even from the folded fp32 weights on the host);
+//   * products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate);
+//   * bias, residual add, LeakyReLU and the MRF mean are evaluated in fp32 and rounded to bf16 once,
+//     where a value is stored (epilogue) or becomes an MFMA operand (LDS staging).
+// The reference has no bf16 path, so its tolerance is unpinned by the reference: tests compare against a CPU
+// restatement with the same rounding points (tests/test_gpu_bf16.py) and report the distance to fp32.
+//
+// Roofline: at bf16 the MRF convs of the C = 32 / 64 stages are HBM-bound (86 / 172 FLOP/B against a
+// machine balance of ~312), C = 128 sits at the ridge and C = 256 stays MFMA-bound.
+//
+// Work split.  A 256-thread block owns (WT*MT*32) time rows x (WC*NT*32) output channels.  The input
+// window (tile + dilated-tap halo) of CIC channels is staged once into LDS as bf16 with the input
+// activation applied; every tap re-reads it at a shifted row.  The MFMA is issued as D = W x X^T:
+//   A operand (weights):     one 16-byte buffer load per lane and (tap, 16 channels, 32-wide C_out tile) from
+//                            the host-packed fragment order, prefetched four groups ahead in a register ring;
+//   B operand (activations): one ds_read_b128 per lane and (tap, 16 channels, 32 rows); LDS row stride
+//                            2*CIC + 16 bytes = 16 * odd -> conflict-free b128 reads and writes;
+//   D: lane = time step, registers 4g..4g+3 = 4 consecutive channels -> 8-byte bf16 stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace iris {
+namespace b16 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+enum InAct : int { IN_ACT_NONE = 0, IN_ACT_LRELU = 1, IN_ACT_MRF_LRELU = 2 };
+
+constexpr int kMaxGroup = 4;
+
+struct Problem {
+    const void* x;        // bf16 [B, L_in, C_in]; fp32 [B, C_in, L_in] when Launch::x_f32_cf (the mel)
+    const void* wp;       // packed bf16 weight fragments, see pack_conv1d_bf16
+    const float* bias;    // [C_out] fp32
+    const uint16_t* res;  // bf16 residual added in the epilogue [B, L_out, C_out], or nullptr
+    uint16_t* y;          // bf16 output [B, L_out, C_out]
+    int ks;               // taps
+    int dil;              // rows between taps
+    int pad_left;         // input row of tap 0 for output row-index i is i - pad_left
+    int reserved;
+};
+
+struct Launch {
+    Problem p[kMaxGroup];
+    const uint16_t* xmrf[kMaxGroup];  // in_act == IN_ACT_MRF_LRELU: input = lrelu((xmrf[0]+...) * (1/n_mrf))
+    int n_mrf;
+    int B, L_in, L_out, C_in, C_out;
+    int n_idx;            // output row-indices (L_out for a conv, L_in + taps - 1 for a ConvTranspose phase)
+    int out_stride;       // output row o = i*out_stride + out_off (+ phase)
+    int out_off;
+    int z_is_phase;       // the z part of blockIdx.x is a ConvTranspose phase of problem 0 (else a problem)
+    unsigned phase_wp_bytes;  // bytes between the packed weights of consecutive phases
+    int in_act;
+    int x_f32_cf;
+    float slope;
+    float inv_n_mrf;
+    int nz;               // problems (or phases) interleaved along blockIdx.x
+    int n_co_blk;         // blocks along C_out
+    int Qp;               // padded number of 16-channel steps in the packed weights
+    int n_ct;             // 32-wide C_out tiles in the packed weights
+};
+
+// ---- small helpers -------------------------------------------------------------------------------
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {   // round to nearest even (v_cvt_pk_bf16_f32)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lrelu1(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store2(u32x2 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+constexpr unsigned kOob = 0x80000000u;   // >= any num_records used here: loads return 0, stores are dropped
+
+// ---- LDS staging ---------------------------------------------------------------------------------
+// Rows [in_row0, in_row0 + R) x channels [c0, c0 + CIC) of the activated input -> LDS (bf16).
+template <int CIC>
+__device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, char* lds, int b,
+                                             int in_row0, int R, int c0) {
+    constexpr int SB = CIC * 2 + 16;
+    constexpr int PPR = CIC / 8;          // 16-byte pieces (8 channels) per row
+    const int tid = threadIdx.x;
+    const int L_in = a.L_in, C_in = a.C_in;
+    if (!a.x_f32_cf) {
+        const unsigned tensor_bytes = (unsigned)L_in * (unsigned)C_in * 2u;
+        const size_t boff = (size_t)b * L_in * C_in;
+        const bool mrf = a.in_act == IN_ACT_MRF_LRELU;
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc((mrf ? a.xmrf[0] : (const uint16_t*)p.x) + boff, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc((mrf && a.n_mrf > 1 ? a.xmrf[1] : a.xmrf[0]) + boff, mrf && a.n_mrf > 1 ? tensor_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t r2 = make_rsrc((mrf && a.n_mrf > 2 ? a.xmrf[2] : a.xmrf[0]) + boff, mrf && a.n_mrf > 2 ? tensor_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t r3 = make_rsrc((mrf && a.n_mrf > 3 ? a.xmrf[3] : a.xmrf[0]) + boff, mrf && a.n_mrf > 3 ? tensor_bytes : 0u);
+        const int total = R * PPR;
+        const float slope = a.in_act == IN_ACT_NONE ? 1.f : a.slope;
+        constexpr int U = 4;              // pieces in flight per thread
+        for (int base = 0; base < total; base += 256 * U) {
+            u32x4 v0[U], v1[U], v2[U], v3[U];
+            int ldso[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx / PPR, pc = idx - r * PPR;
+                const int row = in_row0 + r, ci = c0 + 8 * pc;
+                const bool ok = idx < total && row >= 0 && row < L_in && ci < C_in;
+                const unsigned voff = ok ? (unsigned)(row * C_in + ci) * 2u : kOob;
+                ldso[u] = idx < total ? r * SB + pc * 16 : -1;
+                v0[u] = buf_load4(r0, voff, 0);
+                if (mrf) {
+                    v1[u] = buf_load4(r1, voff, 0);
+                    v2[u] = buf_load4(r2, voff, 0);
+                    v3[u] = buf_load4(r3, voff, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo = bf_lo(v0[u][e]), hi = bf_hi(v0[u][e]);
+                    if (mrf) {
+                        lo += bf_lo(v1[u][e]); hi += bf_hi(v1[u][e]);
+                        lo += bf_lo(v2[u][e]); hi += bf_hi(v2[u][e]);
+                        if (a.n_mrf > 3) { lo += bf_lo(v3[u][e]); hi += bf_hi(v3[u][e]); }
+                        lo *= a.inv_n_mrf; hi *= a.inv_n_mrf;
+                    }
+                    o[e] = pack_bf2(lrelu1(lo, slope), lrelu1(hi, slope));
+                }
+                if (ldso[u] >= 0) *reinterpret_cast<u32x4*>(lds + ldso[u]) = o;
+            }
+        }
+    } else {
+        // the mel: fp32, channels-first [B, C_in, L_in] (hifigan_pretrained.py:228); lanes run along time
+        const float* x = (const float*)p.x;
+        const int total = R * CIC;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int c = idx / R, r = idx - c * R;
+            const int row = in_row0 + r, ci = c0 + c;
+            float v = 0.f;
+            if (row >= 0 && row < L_in && ci < C_in) {
+                v = x[((size_t)b * C_in + ci) * L_in + row];
+                if (a.in_act == IN_ACT_LRELU) v = lrelu1(v, a.slope);
+            }
+            const unsigned pk = pack_bf2(v, 0.f);
+            *reinterpret_cast<uint16_t*>(lds + r * SB + c * 2) = (uint16_t)(pk & 0xffffu);
+        }
+    }
+}
+
+// ---- MFMA main loop over one staged chunk ----------------------------------------------------------
+// One "group" = 16 input channels of one tap = MT*NT MFMAs.  Weight fragments run four groups ahead of
+// their use (register ring); groups past the last tap read beyond the descriptor and get zeros, so the
+// loop needs no tail.  Activation fragments are read one group ahead.
+template <int MT, int NT, int CIC>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const char* a_lane, int dil_bytes,
+                                          __amdgpu_buffer_rsrc_t wr, unsigned wvoff, unsigned q_bytes,
+                                          unsigned tap_bytes, unsigned q0_bytes, int ks) {
+    constexpr int QPC = CIC / 16;
+    constexpr int QL = QPC == 4 ? 2 : (QPC == 2 ? 1 : 0);
+    static_assert(QPC == 4 || QPC == 2 || QPC == 1, "CIC must be 16, 32 or 64");
+    constexpr int SB = CIC * 2 + 16;
+    constexpr int D = 4;
+    const int NG = ks * QPC;
+    auto w_soff = [&](int n) -> unsigned {
+        return (unsigned)(n >> QL) * tap_bytes + q0_bytes + (unsigned)(n & (QPC - 1)) * q_bytes;
+    };
+    auto load_a = [&](u32x4 (&av)[MT], int n) {
+        int tap = n >> QL;
+        tap = tap < ks ? tap : ks - 1;
+        const char* ap = a_lane + tap * dil_bytes + (n & (QPC - 1)) * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const u32x4*>(ap + m * 32 * SB);
+    };
+    u32x4 wv[D][NT], av[2][MT];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(i));
+    load_a(av[0], 0);
+    for (int n0 = 0; n0 < NG; n0 += D) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const int n = n0 + i;
+            load_a(av[(i + 1) & 1], n + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, wv[i][nt]), __builtin_bit_cast(bf16x8, av[i & 1][m]),
+                        acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(n + D));
+        }
+    }
+}
+
+// ---- the kernel -----------------------------------------------------------------------------------
+template <int WT, int WC, int MT, int NT, int CIC>
+__global__ void __launch_bounds__(256, 2) conv_mfma_bf16_kernel(const Launch a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_b16[];
+    char* lds = lds_b16;
+    constexpr int SB = CIC * 2 + 16;
+    constexpr int T_BLK = WT * MT * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = wave / WC, wc = wave - wt * WC;
+    const int lo = lane & 31, hi = lane >> 5;
+
+    // z = MRF branch (heaviest first) or ConvTranspose phase; compile-time indices keep the kernarg in SGPRs
+    const int zr = blockIdx.x % a.nz;
+    const int z = a.z_is_phase ? zr : a.nz - 1 - zr;
+    const int pz = a.z_is_phase ? 0 : z;
+    Problem p = a.p[0];
+    if (pz == 1) p = a.p[1];
+    if (pz == 2) p = a.p[2];
+    if (pz == 3) p = a.p[3];
+    const int out_off = a.out_off + (a.z_is_phase ? z : 0);
+
+    const int bid = blockIdx.x / a.nz;
+    const int tile_co = bid % a.n_co_blk, tile_t = bid / a.n_co_blk;
+    const int b = blockIdx.y;
+    const int i0 = tile_t * T_BLK;
+    const int ks = p.ks;
+    const int R = T_BLK + (ks - 1) * p.dil;
+    const int in_row0 = i0 - p.pad_left;
+    const int ct0 = (tile_co * WC + wc) * NT;        // this wave's first 32-wide C_out tile
+    const bool wave_active = ct0 < a.n_ct;           // wave-uniform
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+
+    const unsigned q_bytes = (unsigned)a.n_ct * 1024u;           // bytes per (tap, 16-channel step)
+    const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
+    const char* wbase = (const char*)p.wp + (a.z_is_phase ? (size_t)z * a.phase_wp_bytes : 0);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wbase, (unsigned)ks * tap_bytes);
+    const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
+    const char* a_lane = lds + (wt * MT * 32 + lo) * SB + hi * 16;
+    const int dil_bytes = p.dil * SB;
+
+    for (int c0 = 0; c0 < a.C_in; c0 += CIC) {
+        if (c0 > 0) __syncthreads();
+        stage_window<CIC>(a, p, lds, b, in_row0, R, c0);
+        __syncthreads();
+        if (wave_active)
+            mma_chunk<MT, NT, CIC>(acc, a_lane, dil_bytes, wr, wvoff, q_bytes, tap_bytes,
+                                   (unsigned)(c0 >> 4) * q_bytes, ks);
+    }
+    if (!wave_active) return;
+
+    // Epilogue: bias + residual in fp32, one rounding to bf16, 8-byte stores (4 channels of one row).
+    const unsigned out_bytes = (unsigned)a.L_out * (unsigned)a.C_out * 2u;
+    const size_t ob = (size_t)b * a.L_out * a.C_out;
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + ob, out_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, p.res ? out_bytes : 0u);
+    unsigned voff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int im = i0 + (wt * MT + m) * 32 + lo;
+        const int o = im * a.out_stride + out_off;
+        const bool ok = im < a.n_idx && o >= 0 && o < a.L_out;
+        voff[m] = ok ? (unsigned)(o * a.C_out + 4 * hi) * 2u : kOob;
+    }
+    u32x2 outp[MT][NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (co < a.C_out) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x2 rv = buf_load2(rr, co < a.C_out ? voff[m] : kOob, (unsigned)((ct0 + nt) * 32 + 8 * g) * 2u);
+                const float v0 = (acc[m][nt][4 * g + 0] + bias4[0]) + bf_lo(rv[0]);
+                const float v1 = (acc[m][nt][4 * g + 1] + bias4[1]) + bf_hi(rv[0]);
+                const float v2 = (acc[m][nt][4 * g + 2] + bias4[2]) + bf_lo(rv[1]);
+                const float v3 = (acc[m][nt][4 * g + 3] + bias4[3]) + bf_hi(rv[1]);
+                outp[m][nt][g][0] = pack_bf2(v0, v1);
+                outp[m][nt][g][1] = pack_bf2(v2, v3);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
+                buf_store2(outp[m][nt][g], yr, co < a.C_out ? voff[m] : kOob, (unsigned)((ct0 + nt) * 32 + 8 * g) * 2u);
+            }
+    __builtin_amdgcn_sched_barrier(0);
+    // the store data must stay live until every store has issued (see the store-data note in
+    // mrf_conv_mfma_f32.h: hipcc otherwise re-uses a store's data VGPRs right behind it)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(outp[m][nt][g]));
+}
+
+// ---- conv_post for bf16 inputs (hifigan_pretrained.py:139-141): fp32 sliding dot product --------------
+struct PostLaunch {
+    const uint16_t* x[kMaxGroup];  // n_in bf16 inputs [B, L, C]; input = lrelu((x[0]+...) * (1/n_in))
+    int n_in;
+    const float* w;                // [k][C] fp32
+    const float* bias;             // [1]
+    float* y;                      // [B, L] fp32
+    int B, L, C, k;
+    float slope, inv_n;
+};
+
+constexpr int kPostTile = 256;
+
+__global__ void __launch_bounds__(256) conv_post_tanh_bf16_kernel(const PostLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_b16[];
+    float* lds = reinterpret_cast<float*>(lds_b16);
+    const int C = a.C, k = a.k, pad = (k - 1) / 2;
+    const int S = C | 1;
+    const int PPR = C / 8;
+    const int b = blockIdx.y, t0 = blockIdx.x * kPostTile;
+    const int R = kPostTile + k - 1;
+    const unsigned tensor_bytes = (unsigned)a.L * (unsigned)C * 2u;
+    const size_t boff = (size_t)b * a.L * C;
+    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(a.x[0] + boff, tensor_bytes);
+    const __amdgpu_buffer_rsrc_t r1 = make_rsrc((a.n_in > 1 ? a.x[1] : a.x[0]) + boff, a.n_in > 1 ? tensor_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t r2 = make_rsrc((a.n_in > 2 ? a.x[2] : a.x[0]) + boff, a.n_in > 2 ? tensor_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t r3 = make_rsrc((a.n_in > 3 ? a.x[3] : a.x[0]) + boff, a.n_in > 3 ? tensor_bytes : 0u);
+    const int total = R * PPR;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int r = idx / PPR, pc = idx - r * PPR;
+        const int row = t0 - pad + r;
+        const unsigned voff = (row >= 0 && row < a.L) ? (unsigned)(row * C + 8 * pc) * 2u : kOob;
+        const u32x4 v0 = buf_load4(r0, voff, 0), v1 = buf_load4(r1, voff, 0), v2 = buf_load4(r2, voff, 0),
+                    v3 = buf_load4(r3, voff, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo = ((bf_lo(v0[e]) + bf_lo(v1[e])) + bf_lo(v2[e])) + bf_lo(v3[e]);
+            float hi = ((bf_hi(v0[e]) + bf_hi(v1[e])) + bf_hi(v2[e])) + bf_hi(v3[e]);
+            if (a.n_in > 1) { lo *= a.inv_n; hi *= a.inv_n; }
+            lds[r * S + 8 * pc + 2 * e] = lrelu1(lo, a.slope);
+            lds[r * S + 8 * pc + 2 * e + 1] = lrelu1(hi, a.slope);
+        }
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= a.L) return;
+    const float* __restrict__ w = a.w;
+    float acc = a.bias[0];
+    for (int kap = 0; kap < k; ++kap) {
+        const float* row = lds + (threadIdx.x + kap) * S;
+        for (int c = 0; c < C; ++c) acc = fmaf(row[c], w[kap * C + c], acc);
+    }
+    a.y[(size_t)b * a.L + t] = tanhf(acc);
+}
+
+inline hipError_t launch_conv_post_bf16(const PostLaunch& a, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)(kPostTile + a.k - 1) * (a.C | 1) * sizeof(float);
+    if (lds_bytes > 160 * 1024 || (a.C & 7)) return hipErrorInvalidValue;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_post_tanh_bf16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)((a.L + kPostTile - 1) / kPostTile), (unsigned)a.B), block(256);
+    hipLaunchKernelGGL(conv_post_tanh_bf16_kernel, grid, block, lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+// ---- host side: weight packing ---------------------------------------------------------------------
+inline uint16_t f32_to_bf16(float f) {   // round to nearest even; weights are finite
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// packed[(((kap*Qp + q)*n_ct + ct)*64 + lane)*8 + e]
+//     = bf16(W[co = ct*32 + (lane&31)][ci = 16q + 8*(lane>>5) + e][kap])      (0 outside C_out / C_in)
+// Qp = 16-channel steps padded to a multiple of 4 (64 channels) so that any chunking stays inside.
+inline int packed_qsteps(int C_in) { return ((C_in + 63) / 64) * 4; }
+inline int packed_cotiles(int C_out) { return (C_out + 31) / 32; }
+inline size_t packed_conv1d_halfs(int C_in, int C_out, int ks) {
+    return (size_t)ks * packed_qsteps(C_in) * packed_cotiles(C_out) * 64 * 8;
+}
+// w: reference Conv1d layout [C_out][C_in][ks] (hifigan_pretrained.py:50-57)
+inline void pack_conv1d_bf16(const float* w, int C_in, int C_out, int ks, uint16_t* out) {
+    const int Qp = packed_qsteps(C_in), n_ct = packed_cotiles(C_out);
+    for (int kap = 0; kap < ks; ++kap)
+        for (int q = 0; q < Qp; ++q)
+            for (int ct = 0; ct < n_ct; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = ct * 32 + (lane & 31);
+                        const int ci = 16 * q + 8 * (lane >> 5) + e;
+                        float v = 0.f;
+                        if (co < C_out && ci < C_in) v = w[((size_t)co * C_in + ci) * ks + kap];
+                        out[((((size_t)kap * Qp + q) * n_ct + ct) * 64 + lane) * 8 + e] = f32_to_bf16(v);
+                    }
+}
+// ConvTranspose1d weights [C_in][C_out][k] (hifigan_pretrained.py:101-107) as u phase convolutions with
+// ceil(k/u) taps each; tap kap of phase ph holds w[:, :, ph + (taps-1-kap)*u] (see conv_mfma_f32.h).
+inline int convt_taps(int k, int u) { return (k + u - 1) / u; }
+inline size_t packed_convt_phase_halfs(int C_in, int C_out, int k, int u) {
+    return packed_conv1d_halfs(C_in, C_out, convt_taps(k, u));
+}
+inline void pack_convt_bf16(const float* w, int C_in, int C_out, int k, int u, uint16_t* out) {
+    const int taps = convt_taps(k, u);
+    const int Qp = packed_qsteps(C_in), n_ct = packed_cotiles(C_out);
+    const size_t phase_halfs = packed_convt_phase_halfs(C_in, C_out, k, u);
+    for (int ph = 0; ph < u; ++ph)
+        for (int kap = 0; kap < taps; ++kap) {
+            const int kk = ph + (taps - 1 - kap) * u;
+            for (int q = 0; q < Qp; ++q)
+                for (int ct = 0; ct < n_ct; ++ct)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = ct * 32 + (lane & 31);
+                            const int ci = 16 * q + 8 * (lane >> 5) + e;
+                            float v = 0.f;
+                            if (co < C_out && ci < C_in && kk < k) v = w[((size_t)ci * C_out + co) * k + kk];
+                            out[ph * phase_halfs + ((((size_t)kap * Qp + q) * n_ct + ct) * 64 + lane) * 8 + e] =
+                                f32_to_bf16(v);
+                        }
+        }
+}
+
+// ---- launch ----------------------------------------------------------------------------------------
+struct Tile { int WT, WC, MT, NT, CIC, T_BLK, CO_BLK; };
+
+inline Tile pick_tile(int C_in, int C_out) {
+    Tile t;
+    if (C_out <= 32)      { t.WT = 4; t.WC = 1; t.MT = 4; t.NT = 1; }
+    else if (C_out <= 64) { t.WT = 4; t.WC = 1; t.MT = 2; t.NT = 2; }
+    else                  { t.WT = 2; t.WC = 2; t.MT = 2; t.NT = 2; }
+    t.CIC = (C_in <= 32) ? 32 : 64;
+    t.T_BLK = t.WT * t.MT * 32;
+    t.CO_BLK = t.WC * t.NT * 32;
+    return t;
+}
+
+// Fills the derived fields of `a` and launches.  `nz` = problems or phases.
+inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
+    const Tile t = pick_tile(a.C_in, a.C_out);
+    a.n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
+    a.Qp = packed_qsteps(a.C_in);
+    a.n_ct = packed_cotiles(a.C_out);
+    a.nz = nz;
+    a.inv_n_mrf = a.n_mrf > 0 ? 1.0f / (float)a.n_mrf : 1.0f;
+    int span = 0;
+    const int np = a.z_is_phase ? 1 : nz;
+    if (np > kMaxGroup) return hipErrorInvalidValue;
+    for (int j = 0; j < np; ++j) {
+        const int s = (a.p[j].ks - 1) * a.p[j].dil;
+        if (s > span) span = s;
+    }
+    // 32-bit byte offsets inside one batch item's tensor (buffer descriptors)
+    if ((double)a.L_in * a.C_in * 2.0 >= 2147483648.0 || (double)a.L_out * a.C_out * 2.0 >= 2147483648.0)
+        return hipErrorInvalidValue;
+    if (!a.x_f32_cf && (a.C_in & 7)) return hipErrorInvalidValue;
+    if (a.C_out & 3) return hipErrorInvalidValue;
+    const size_t lds_bytes = (size_t)(t.T_BLK + span) * (t.CIC * 2 + 16);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
+    dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
+#define IRIS_B16_LAUNCH(...)                                                                      \
+    do {                                                                                          \
+        auto kfn = __VA_ARGS__;                                                                   \
+        if (lds_bytes > 64 * 1024) {                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               (int)lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+    } while (0)
+    if (t.NT == 1 && t.CIC == 32)      IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 4, 1, 32>);
+    else if (t.NT == 1)                IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 4, 1, 64>);
+    else if (t.WC == 1)                IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 2, 2, 64>);
+    else                               IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<2, 2, 2, 2, 64>);
+#undef IRIS_B16_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace b16
+}  // namespace iris

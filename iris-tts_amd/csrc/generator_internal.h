@@ -1,0 +1,131 @@
+// generator_internal.h -- state shared by the translation units behind include/iris_hifigan.h
+// (iris_hifigan.hip: C-ABI + fp32 path; iris_hifigan_bf16.hip: bf16-storage path).  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <utility>
+#include <vector>
+
+#include "../../include/iris_hifigan.h"
+
+namespace iris {
+
+// records the message for iris_hifigan_last_error() and returns `code`
+int fail(int code, const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return ::iris::fail(IRIS_HIFIGAN_HIP_ERROR, "%s failed: %s (%s:%d)", #expr,      \
+                                hipGetErrorString(e__), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define TRY(expr) do { int rc__ = (expr); if (rc__ != IRIS_HIFIGAN_OK) return rc__; } while (0)
+
+struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on the device
+    int kind = 0;                                     // 0 Conv1d, 1 ConvTranspose1d, 2 conv_post
+    int C_in = 0, C_out = 0, k = 0, dil = 1, u = 1;  // u = stride of a ConvTranspose1d
+    size_t w_off = 0, b_off = 0;                      // float offsets into the device blob
+    size_t w_floats = 0;                              // packed size
+    size_t ref_w_floats = 0;                          // size in the reference layout
+    size_t w16_off = 0, w16_halfs = 0;                // bf16 path: offset/size (bf16 elements) in blob16
+};
+
+struct Stage {
+    ConvLayer up;
+    int C = 0;             // channels after the upsample
+    int rate = 1;
+    // convs[j][m][0|1] = resblocks[i*nk + j].convs{1,2}[m]
+    std::vector<std::vector<ConvLayer>> c1, c2;
+};
+
+}  // namespace iris
+
+struct iris_hifigan_handle {
+    iris_hifigan_config cfg;
+    iris::ConvLayer pre, post;
+    std::vector<iris::Stage> stages;
+    float* blob = nullptr;   // device: packed fp32 weights + biases
+    size_t blob_floats = 0;
+    uint16_t* blob16 = nullptr;  // device: packed bf16 weights (biases stay fp32 in `blob`)
+    size_t blob16_halfs = 0;
+    int hop = 1;
+    int device = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;          // event pool, n_ev in use
+    size_t n_ev = 0;
+    std::vector<iris_hifigan_launch_record> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec_ev;  // (start, end) event of each record
+    int n_rec = 0;
+};
+
+namespace iris {
+
+// Walks the layers in blob order; fn(layer&) for each.
+template <class Fn>
+void for_each_layer(iris_hifigan_handle* h, Fn fn) {
+    fn(h->pre);
+    for (auto& st : h->stages) {
+        fn(st.up);
+        for (size_t j = 0; j < st.c1.size(); ++j) {
+            for (auto& l : st.c1[j]) fn(l);
+            for (auto& l : st.c2[j]) fn(l);
+        }
+    }
+    fn(h->post);
+}
+
+// Launch timing with ONE event per launch boundary: event e_k sits between launch k-1 and launch k
+// of a forward, so launch k lasted elapsed(e_k, e_{k+1}) (its start-up gap included).  A forward of
+// n launches records n + 1 events.
+struct Prof {
+    iris_hifigan_handle* h;
+    hipStream_t stream;
+    int idx = 0;        // next record
+    bool open = false;  // a start event for the next launch is already on the stream
+    int mark(hipEvent_t* out) {
+        if (h->n_ev >= h->ev.size()) {
+            const size_t old = h->ev.size();
+            h->ev.resize(old + 64);
+            for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+        }
+        *out = h->ev[h->n_ev++];
+        HIP_TRY(hipEventRecord(*out, stream));
+        return IRIS_HIFIGAN_OK;
+    }
+    int begin(int kind, int stage, int step, double flops, double bytes) {
+        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        if ((size_t)idx >= h->recs.size()) { h->recs.resize(idx + 64); h->rec_ev.resize(idx + 64); }
+        iris_hifigan_launch_record& r = h->recs[idx];
+        memset(&r, 0, sizeof(r));
+        r.kind = kind; r.stage = stage; r.step = step; r.flops = flops; r.bytes = bytes;
+        if (!open) {
+            int rc = mark(&h->rec_ev[idx].first);
+            if (rc != IRIS_HIFIGAN_OK) return rc;
+        } else {
+            h->rec_ev[idx].first = h->rec_ev[idx - 1].second;
+        }
+        return IRIS_HIFIGAN_OK;
+    }
+    int end() {
+        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        int rc = mark(&h->rec_ev[idx].second);
+        if (rc != IRIS_HIFIGAN_OK) return rc;
+        open = true;
+        ++idx;
+        return IRIS_HIFIGAN_OK;
+    }
+};
+
+// ---- bf16-storage path (iris_hifigan_bf16.hip) ----
+int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob16
+uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T);
+int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
+                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream);
+
+}  // namespace iris

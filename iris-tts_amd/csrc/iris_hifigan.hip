@@ -22,7 +22,7 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/iris_hifigan.h"
+#include "generator_internal.h"
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
 #include "conv_post.h"
@@ -30,7 +30,7 @@
 
 using namespace iris;
 
-namespace {
+namespace iris {
 
 thread_local char g_err[512] = "";
 
@@ -42,48 +42,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
-            return fail(IRIS_HIFIGAN_HIP_ERROR, "%s failed: %s (%s:%d)", #expr,              \
-                        hipGetErrorString(e__), __FILE__, __LINE__);                         \
-    } while (0)
-
-struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on the device
-    int kind = 0;                                     // 0 Conv1d, 1 ConvTranspose1d, 2 conv_post
-    int C_in = 0, C_out = 0, k = 0, dil = 1, u = 1;  // u = stride of a ConvTranspose1d
-    size_t w_off = 0, b_off = 0;                      // float offsets into the device blob
-    size_t w_floats = 0;                              // packed size
-    size_t ref_w_floats = 0;                          // size in the reference layout
-};
-
-struct Stage {
-    ConvLayer up;
-    int C = 0;             // channels after the upsample
-    int rate = 1;
-    // convs[j][m][0|1] = resblocks[i*nk + j].convs{1,2}[m]
-    std::vector<std::vector<ConvLayer>> c1, c2;
-};
-
-}  // namespace
-
-struct iris_hifigan_handle {
-    iris_hifigan_config cfg;
-    ConvLayer pre, post;
-    std::vector<Stage> stages;
-    float* blob = nullptr;   // device: packed weights + biases
-    size_t blob_floats = 0;
-    int hop = 1;
-    int device = 0;
-    // profiling
-    bool profiling = false;
-    std::vector<hipEvent_t> ev;          // event pool, n_ev in use
-    size_t n_ev = 0;
-    std::vector<iris_hifigan_launch_record> recs;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> rec_ev;  // (start, end) event of each record
-    int n_rec = 0;
-};
+}  // namespace iris
 
 namespace {
 
@@ -121,20 +80,6 @@ int validate(const iris_hifigan_config* c) {
         !(c->post_kernel_size & 1))
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "pre/post kernel sizes must be odd");
     return IRIS_HIFIGAN_OK;
-}
-
-// Walks the layers in blob order; fn(layer&) for each.
-template <class Fn>
-void for_each_layer(iris_hifigan_handle* h, Fn fn) {
-    fn(h->pre);
-    for (auto& st : h->stages) {
-        fn(st.up);
-        for (size_t j = 0; j < st.c1.size(); ++j) {
-            for (auto& l : st.c1[j]) fn(l);
-            for (auto& l : st.c2[j]) fn(l);
-        }
-    }
-    fn(h->post);
 }
 
 void build_layers(iris_hifigan_handle* h) {
@@ -217,50 +162,6 @@ WsLayout ws_layout(const iris_hifigan_handle* h, int B, int T) {
     return w;
 }
 
-// Launch timing with ONE event per launch boundary: event e_k sits between launch k-1 and launch k
-// of a forward, so launch k lasted elapsed(e_k, e_{k+1}) (its start-up gap included).  A forward of
-// n launches records n + 1 events.
-struct Prof {
-    iris_hifigan_handle* h;
-    hipStream_t stream;
-    int idx = 0;        // next record
-    bool open = false;  // a start event for the next launch is already on the stream
-    int mark(hipEvent_t* out) {
-        if (h->n_ev >= h->ev.size()) {
-            const size_t old = h->ev.size();
-            h->ev.resize(old + 64);
-            for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
-        }
-        *out = h->ev[h->n_ev++];
-        HIP_TRY(hipEventRecord(*out, stream));
-        return IRIS_HIFIGAN_OK;
-    }
-    int begin(int kind, int stage, int step, double flops, double bytes) {
-        if (!h->profiling) return IRIS_HIFIGAN_OK;
-        if ((size_t)idx >= h->recs.size()) { h->recs.resize(idx + 64); h->rec_ev.resize(idx + 64); }
-        iris_hifigan_launch_record& r = h->recs[idx];
-        memset(&r, 0, sizeof(r));
-        r.kind = kind; r.stage = stage; r.step = step; r.flops = flops; r.bytes = bytes;
-        if (!open) {
-            int rc = mark(&h->rec_ev[idx].first);
-            if (rc != IRIS_HIFIGAN_OK) return rc;
-        } else {
-            h->rec_ev[idx].first = h->rec_ev[idx - 1].second;
-        }
-        return IRIS_HIFIGAN_OK;
-    }
-    int end() {
-        if (!h->profiling) return IRIS_HIFIGAN_OK;
-        int rc = mark(&h->rec_ev[idx].second);
-        if (rc != IRIS_HIFIGAN_OK) return rc;
-        open = true;
-        ++idx;
-        return IRIS_HIFIGAN_OK;
-    }
-};
-
-#define TRY(expr) do { int rc__ = (expr); if (rc__ != IRIS_HIFIGAN_OK) return rc__; } while (0)
-
 void init_launch(ConvLaunch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
 
 }  // namespace
@@ -268,7 +169,7 @@ void init_launch(ConvLaunch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
 extern "C" {
 
 int32_t iris_hifigan_abi_version(void) { return IRIS_HIFIGAN_ABI_VERSION; }
-const char* iris_hifigan_last_error(void) { return g_err; }
+const char* iris_hifigan_last_error(void) { return iris::g_err; }
 
 int32_t iris_hifigan_weight_count(const iris_hifigan_config* cfg, uint64_t* count) {
     TRY(validate(cfg));
@@ -321,6 +222,12 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "weight upload failed: %s", hipGetErrorString(e));
     }
+    const int rc16 = bf16_build_blob(h, weights_host);
+    if (rc16 != IRIS_HIFIGAN_OK) {
+        (void)hipFree(h->blob);
+        delete h;
+        return rc16;
+    }
     *out = h;
     return IRIS_HIFIGAN_OK;
 }
@@ -329,6 +236,7 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     if (!h) return IRIS_HIFIGAN_OK;
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     if (h->blob) (void)hipFree(h->blob);
+    if (h->blob16) (void)hipFree(h->blob16);
     delete h;
     return IRIS_HIFIGAN_OK;
 }
@@ -343,6 +251,7 @@ int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, in
                                      int32_t dtype, uint64_t* bytes) {
     if (!h || !bytes) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    if (dtype == IRIS_HIFIGAN_BF16) { *bytes = bf16_workspace_bytes(h, B, T); return IRIS_HIFIGAN_OK; }
     if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     *bytes = ws_layout(h, B, T).total * sizeof(float);
     return IRIS_HIFIGAN_OK;
@@ -373,13 +282,16 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                              void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
                              int32_t dtype, void* stream_) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
-    if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
     if (!mel_dev || !wav_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
     if (B > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "batch %d exceeds 65535 (grid.y)", B);
     if ((int64_t)T * h->hop > (int64_t)1 << 30)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "T*hop = %lld exceeds 2^30 rows", (long long)T * h->hop);
+    if (dtype == IRIS_HIFIGAN_BF16)
+        return bf16_forward(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, (hipStream_t)stream_);
     const WsLayout w = ws_layout(h, B, T);
     if (workspace_bytes < w.total * sizeof(float))
         return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",

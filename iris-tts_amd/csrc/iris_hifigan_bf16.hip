@@ -1,0 +1,263 @@
+// iris_hifigan_bf16.hip -- the bf16-storage generator forward (dtype IRIS_HIFIGAN_BF16) behind
+// iris_hifigan_forward.  Same launch plan as the fp32 path (iris_hifigan.hip; reference
+// HiFiGANModel.forward, src/iris/hifigan_pretrained.py:123-143):
+//   conv_pre (reads the fp32 channels-first mel) -> per stage { upsample (u phases), 2*num_dilations
+//   grouped MRF launches } -> conv_post + tanh (fp32 waveform out).
+// The MRF mean is formed by the consumer of a stage while it stages its input (SURVEY.md 8d accounting L).
+#include "generator_internal.h"
+#include "conv_mfma_bf16.h"
+
+namespace iris {
+
+using namespace b16;
+
+namespace {
+
+struct Ws16 {            // bf16 elements
+    size_t pre, up, y[IRIS_HIFIGAN_MAX_KERNELS], xt[IRIS_HIFIGAN_MAX_KERNELS], total;
+};
+
+Ws16 ws16_layout(const iris_hifigan_handle* h, int B, int T) {
+    Ws16 w;
+    const size_t frames = (size_t)B * T;
+    size_t per_frame_max = 0, L = 1;
+    for (const auto& st : h->stages) {
+        L *= st.rate;
+        const size_t e = L * st.C;
+        if (e > per_frame_max) per_frame_max = e;
+    }
+    size_t off = 0;
+    auto take = [&](size_t halfs) { size_t o = off; off += (halfs + 127) & ~(size_t)127; return o; };
+    w.pre = take(frames * h->pre.C_out);
+    w.up = take(frames * per_frame_max);
+    for (int j = 0; j < h->cfg.num_kernels; ++j) {
+        w.y[j] = take(frames * per_frame_max);
+        w.xt[j] = take(frames * per_frame_max);
+    }
+    w.total = off;
+    return w;
+}
+
+void init_launch(Launch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
+
+}  // namespace
+
+int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host) {
+    // every channel count of the bf16 path must be a multiple of 8 (16-byte bf16 pieces)
+    bool ok = h->cfg.num_kernels <= kMaxGroup && (h->pre.C_out % 8) == 0;
+    for (const auto& st : h->stages) ok = ok && (st.C % 8) == 0;
+    if (!ok) { h->blob16 = nullptr; h->blob16_halfs = 0; return IRIS_HIFIGAN_OK; }   // bf16 forward reports UNSUPPORTED
+    size_t off = 0;
+    for_each_layer(h, [&](ConvLayer& l) {
+        if (l.kind == 2)      l.w16_halfs = 0;                      // conv_post keeps fp32 weights
+        else if (l.kind == 1) l.w16_halfs = packed_convt_phase_halfs(l.C_in, l.C_out, l.k, l.u) * l.u;
+        else                  l.w16_halfs = packed_conv1d_halfs(l.C_in, l.C_out, l.k);
+        l.w16_off = off;
+        off += (l.w16_halfs + 127) & ~(size_t)127;
+    });
+    h->blob16_halfs = off;
+    std::vector<uint16_t> host(off, 0);
+    const float* src = weights_host;
+    for_each_layer(h, [&](ConvLayer& l) {
+        uint16_t* dst = host.data() + l.w16_off;
+        if (l.kind == 1)      pack_convt_bf16(src, l.C_in, l.C_out, l.k, l.u, dst);
+        else if (l.kind == 0) pack_conv1d_bf16(src, l.C_in, l.C_out, l.k, dst);
+        src += l.ref_w_floats + l.C_out;
+    });
+    hipError_t e = hipMalloc(&h->blob16, off * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(h->blob16, host.data(), off * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->blob16) (void)hipFree(h->blob16);
+        h->blob16 = nullptr;
+        return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
+                    "bf16 weight upload failed: %s", hipGetErrorString(e));
+    }
+    return IRIS_HIFIGAN_OK;
+}
+
+uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T) {
+    return ws16_layout(h, B, T).total * sizeof(uint16_t);
+}
+
+int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
+                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream) {
+    if (!h->blob16)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 path needs channel counts that are multiples of 8 and at most %d MRF kernels", kMaxGroup);
+    const Ws16 w = ws16_layout(h, B, T);
+    if (workspace_bytes < w.total * sizeof(uint16_t))
+        return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
+                    (unsigned long long)workspace_bytes, (unsigned long long)(w.total * sizeof(uint16_t)));
+    uint16_t* ws = (uint16_t*)workspace_dev;
+    const uint16_t* wb = h->blob16;
+    const float* blob = h->blob;
+    const float slope = h->cfg.lrelu_slope;
+    const int nk = h->cfg.num_kernels;
+    Prof prof{h, stream, h->profiling ? h->n_rec : 0};
+    const double fB = (double)B;
+
+    // ---- conv_pre (hifigan_pretrained.py:124): fp32 mel in, bf16 out ----
+    {
+        Launch a; init_launch(a);
+        const ConvLayer& l = h->pre;
+        a.p[0].x = mel_dev; a.p[0].wp = wb + l.w16_off; a.p[0].bias = blob + l.b_off;
+        a.p[0].res = nullptr; a.p[0].y = ws + w.pre;
+        a.p[0].ks = l.k; a.p[0].dil = 1; a.p[0].pad_left = (l.k - 1) / 2;
+        a.B = B; a.L_in = T; a.L_out = T; a.C_in = l.C_in; a.C_out = l.C_out; a.n_idx = T;
+        a.in_act = IN_ACT_NONE; a.x_f32_cf = 1; a.slope = slope;
+        TRY(prof.begin(0, -1, 0, 2.0 * fB * T * l.C_in * l.C_out * l.k,
+                       fB * T * (4.0 * l.C_in + 2.0 * l.C_out) + 2.0 * (double)l.ref_w_floats + 4.0 * l.C_out));
+        HIP_TRY(launch_conv_bf16(a, 1, stream));
+        TRY(prof.end());
+    }
+
+    int L = T;
+    for (size_t i = 0; i < h->stages.size(); ++i) {
+        const Stage& st = h->stages[i];
+        const int L_out = L * st.rate;
+        // ---- LeakyReLU + ConvTranspose1d (hifigan_pretrained.py:127-128) ----
+        {
+            Launch a; init_launch(a);
+            const ConvLayer& l = st.up;
+            const int taps = convt_taps(l.k, l.u);
+            a.p[0].wp = wb + l.w16_off; a.p[0].bias = blob + l.b_off;
+            a.p[0].res = nullptr; a.p[0].y = ws + w.up;
+            a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
+            const int n_in = i == 0 ? 1 : nk;
+            if (i == 0) { a.p[0].x = ws + w.pre; a.in_act = IN_ACT_LRELU; }
+            else {
+                a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk;
+                for (int j = 0; j < nk; ++j) a.xmrf[j] = ws + w.y[j];
+                a.p[0].x = a.xmrf[0];
+            }
+            a.B = B; a.L_in = L; a.L_out = L_out; a.C_in = l.C_in; a.C_out = l.C_out;
+            a.n_idx = L + taps - 1; a.out_stride = l.u; a.out_off = -(l.k - l.u) / 2;
+            a.z_is_phase = 1;
+            a.phase_wp_bytes = (unsigned)(packed_convt_phase_halfs(l.C_in, l.C_out, l.k, l.u) * 2);
+            a.slope = slope;
+            TRY(prof.begin(1, (int)i, 0, 2.0 * fB * L * l.C_in * l.C_out * l.k,
+                           2.0 * (fB * L * l.C_in * n_in + fB * L_out * l.C_out + (double)l.ref_w_floats) + 4.0 * l.C_out));
+            HIP_TRY(launch_conv_bf16(a, l.u, stream));
+            TRY(prof.end());
+        }
+        // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----
+        const int nd = h->cfg.num_dilations[0];
+        const double n_el = fB * L_out * st.C;
+        for (int m = 0; m < nd; ++m) {
+            for (int half = 0; half < 2; ++half) {
+                Launch a; init_launch(a);
+                double flops = 0, wbytes = 0;
+                for (int j = 0; j < nk; ++j) {
+                    const ConvLayer& l = half == 0 ? st.c1[j][m] : st.c2[j][m];
+                    Problem& p = a.p[j];
+                    const uint16_t* cur = (m == 0) ? ws + w.up : ws + w.y[j];  // x entering this pair
+                    if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
+                    else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
+                    p.wp = wb + l.w16_off; p.bias = blob + l.b_off;
+                    p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
+                    flops += 2.0 * n_el * l.C_in * l.k;
+                    wbytes += 2.0 * (double)l.ref_w_floats + 4.0 * l.C_out;
+                }
+                a.B = B; a.L_in = L_out; a.L_out = L_out; a.C_in = st.C; a.C_out = st.C;
+                a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
+                TRY(prof.begin(2, (int)i, 2 * m + half, flops, 2.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
+                HIP_TRY(launch_conv_bf16(a, nk, stream));
+                TRY(prof.end());
+            }
+        }
+        L = L_out;
+    }
+
+    // ---- LeakyReLU + conv_post + tanh (hifigan_pretrained.py:139-141): bf16 in, fp32 waveform out ----
+    {
+        PostLaunch a; memset(&a, 0, sizeof(a));
+        const ConvLayer& l = h->post;
+        for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+        a.n_in = nk; a.inv_n = 1.0f / (float)nk;
+        a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
+        a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope;
+        TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
+                       2.0 * fB * L * l.C_in * nk + 4.0 * (fB * L + (double)l.ref_w_floats + 1)));
+        HIP_TRY(launch_conv_post_bf16(a, stream));
+        TRY(prof.end());
+    }
+    h->n_rec = prof.idx;
+    return IRIS_HIFIGAN_OK;
+}
+
+}  // namespace iris
+
+// ------------------------------------------------------------------------------------------------
+// single-layer entry points (parity tests of the bf16 kernel)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DevBytes {
+    void* p = nullptr;
+    ~DevBytes() { if (p) (void)hipFree(p); }
+    hipError_t upload(const void* src, size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
+                                    const void* res_dev, void* y_dev, int32_t B, int32_t L, int32_t C_in,
+                                    int32_t C_out, int32_t k, int32_t dilation, int32_t in_act, float slope,
+                                    void* stream_) {
+    using namespace iris;
+    using namespace iris::b16;
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || k < 1 || !(k & 1) || dilation < 1 || B > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv1d shape");
+    if ((C_in & 7) || (C_out & 3))
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 conv needs C_in %% 8 == 0 and C_out %% 4 == 0");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<uint16_t> packed(packed_conv1d_halfs(C_in, C_out, k));
+    pack_conv1d_bf16(w_host, C_in, C_out, k, packed.data());
+    DevBytes wb, bb;
+    HIP_TRY(wb.upload(packed.data(), packed.size() * sizeof(uint16_t)));
+    HIP_TRY(bb.upload(bias_host, sizeof(float) * C_out));
+    Launch a; memset(&a, 0, sizeof(a)); a.out_stride = 1;
+    a.p[0].x = x_dev; a.p[0].wp = wb.p; a.p[0].bias = (const float*)bb.p; a.p[0].res = (const uint16_t*)res_dev;
+    a.p[0].y = (uint16_t*)y_dev; a.p[0].ks = k; a.p[0].dil = dilation; a.p[0].pad_left = dilation * (k - 1) / 2;
+    a.B = B; a.L_in = L; a.L_out = L; a.C_in = C_in; a.C_out = C_out; a.n_idx = L;
+    a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
+    HIP_TRY(launch_conv_bf16(a, 1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
+                                              void* y_dev, int32_t B, int32_t L, int32_t C_in, int32_t C_out,
+                                              int32_t k, int32_t u, int32_t in_act, float slope, void* stream_) {
+    using namespace iris;
+    using namespace iris::b16;
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || u < 1 || k < u || ((k - u) & 1) || B > 65535 || u > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_transpose1d shape");
+    if ((C_in & 7) || (C_out & 3))
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 conv needs C_in %% 8 == 0 and C_out %% 4 == 0");
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t phase_halfs = packed_convt_phase_halfs(C_in, C_out, k, u);
+    std::vector<uint16_t> packed(phase_halfs * u);
+    pack_convt_bf16(w_host, C_in, C_out, k, u, packed.data());
+    DevBytes wb, bb;
+    HIP_TRY(wb.upload(packed.data(), packed.size() * sizeof(uint16_t)));
+    HIP_TRY(bb.upload(bias_host, sizeof(float) * C_out));
+    const int taps = convt_taps(k, u);
+    Launch a; memset(&a, 0, sizeof(a));
+    a.p[0].x = x_dev; a.p[0].wp = wb.p; a.p[0].bias = (const float*)bb.p; a.p[0].res = nullptr;
+    a.p[0].y = (uint16_t*)y_dev; a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
+    a.B = B; a.L_in = L; a.L_out = L * u; a.C_in = C_in; a.C_out = C_out; a.n_idx = L + taps - 1;
+    a.out_stride = u; a.out_off = -(k - u) / 2; a.z_is_phase = 1;
+    a.phase_wp_bytes = (unsigned)(phase_halfs * 2);
+    a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
+    HIP_TRY(launch_conv_bf16(a, u, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+}  // extern "C"

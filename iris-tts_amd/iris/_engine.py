@@ -17,6 +17,14 @@ from . import _native
 from ._weights import GeneratorConfig, expected_weight_count, weight_blob
 
 KIND_NAMES = {0: "conv_pre", 1: "upsample", 2: "mrf_resblock_conv", 3: "conv_post"}
+DTYPES = {"f32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16}
+
+
+def _dtype_code(dtype: str) -> int:
+    try:
+        return DTYPES[dtype]
+    except KeyError:
+        raise ValueError(f"dtype must be one of {sorted(DTYPES)}, got {dtype!r}") from None
 
 
 def require_gpu() -> torch.device:
@@ -66,10 +74,10 @@ class GeneratorEngine:
             pass
 
     # -- forward -----------------------------------------------------------------------------
-    def workspace_bytes(self, batch: int, frames: int) -> int:
+    def workspace_bytes(self, batch: int, frames: int, dtype: str = "f32") -> int:
         n = ctypes.c_uint64()
         _native.check("iris_hifigan_workspace_bytes", self.lib.iris_hifigan_workspace_bytes(
-            self._handle, batch, frames, _native.DTYPE_F32, ctypes.byref(n)))
+            self._handle, batch, frames, _dtype_code(dtype), ctypes.byref(n)))
         return int(n.value)
 
     def _get_workspace(self, nbytes: int) -> torch.Tensor:
@@ -78,9 +86,12 @@ class GeneratorEngine:
             self._workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: str = "f32") -> torch.Tensor:
         """mel: fp32 device tensor [B, in_channels, T] -> waveform fp32 [B, hop*T] (asynchronous on
-        the current stream)."""
+        the current stream).  ``dtype`` selects the storage/arithmetic of the layers in between: "f32" (the
+        parity path, <= 1e-4 against the reference) or "bf16" (bf16 activations and weights, fp32
+        accumulation; BASELINE.json configs[2])."""
+        code = _dtype_code(dtype)
         if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
             raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
         if mel.device != self.device:
@@ -93,19 +104,19 @@ class GeneratorEngine:
             raise ValueError("out must be a contiguous fp32 tensor [B, hop*T]")
         if batch == 0 or frames == 0:
             return out
-        nbytes = self.workspace_bytes(batch, frames)
+        nbytes = self.workspace_bytes(batch, frames, dtype)
         ws = self._get_workspace(nbytes)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _native.check("iris_hifigan_forward", self.lib.iris_hifigan_forward(
             self._handle, ctypes.c_void_p(mel.data_ptr()), batch, frames, ctypes.c_void_p(out.data_ptr()),
-            ctypes.c_void_p(ws.data_ptr()), ctypes.c_uint64(ws.numel()), _native.DTYPE_F32,
+            ctypes.c_void_p(ws.data_ptr()), ctypes.c_uint64(ws.numel()), code,
             ctypes.c_void_p(stream)))
         return out
 
     __call__ = forward
 
     # -- hipGraph replay ---------------------------------------------------------------------------
-    def forward_graph(self, mel: torch.Tensor) -> torch.Tensor:
+    def forward_graph(self, mel: torch.Tensor, dtype: str = "f32") -> torch.Tensor:
         """Same result as ``forward`` but the launches of one forward are captured once per
         (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 30
         kernel launches, and the inter-kernel gaps shrink to the graph's own.  ``iris_hifigan_forward`` is
@@ -116,31 +127,31 @@ class GeneratorEngine:
             raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
         batch, _, frames = mel.shape
         if batch == 0 or frames == 0:
-            return self.forward(mel)
-        key = (batch, frames)
+            return self.forward(mel, dtype=dtype)
+        key = (batch, frames, dtype)
         entry = self._graphs.get(key)
         if entry is None:
             static_in = torch.empty((batch, self.cfg.in_channels, frames), dtype=torch.float32, device=self.device)
             static_out = torch.empty((batch, frames * self.hop_length), dtype=torch.float32, device=self.device)
-            self._get_workspace(self.workspace_bytes(batch, frames))     # allocate before capture
+            self._get_workspace(self.workspace_bytes(batch, frames, dtype))     # allocate before capture
             ws_ptr = self._workspace.data_ptr()
             static_in.copy_(mel)
             self.set_profiling(False)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                                # warm-up outside capture
-                self.forward(static_in, out=static_out)
+                self.forward(static_in, out=static_out, dtype=dtype)
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self.forward(static_in, out=static_out)
+                self.forward(static_in, out=static_out, dtype=dtype)
             entry = (graph, static_in, static_out, ws_ptr)
             self._graphs[key] = entry
         graph, static_in, static_out, ws_ptr = entry
         if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
             # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
             del self._graphs[key]
-            return self.forward_graph(mel)
+            return self.forward_graph(mel, dtype=dtype)
         static_in.copy_(mel.to(device=self.device, dtype=torch.float32))
         graph.replay()
         return static_out

@@ -26,6 +26,9 @@ pinned against outputs of the reference itself, generated in the build container
 committed under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks both implementations
 against them.  The Keras/JAX twin cannot be executed anywhere in this pipeline: for it the oracle
 is the same function under the documented parameter map -- "parity unpinned" for that twin.
+``generator_forward_bf16`` restates the bf16-storage variant (BASELINE.json configs[2]); the reference
+has no bf16 path, so that function is "parity unpinned" too: it defines the variant's rounding points and
+tests report its distance to the pinned fp32 functions.
 """
 from __future__ import annotations
 
@@ -222,6 +225,65 @@ def generator_forward_torch(folded_t: Mapping[str, object], mel, cfg: Optional[O
                     r = xt + r
                 xs = r if xs is None else xs + r
             x = xs / cfg.num_kernels
+            if taps is not None:
+                taps[f"mrf.{i}"] = x
+        x = F.leaky_relu(x, slope)
+        kp = folded_t["conv_post.weight"].shape[-1]
+        x = F.conv1d(x, folded_t["conv_post.weight"], folded_t["conv_post.bias"], padding=(kp - 1) // 2)
+        return torch.tanh(x)
+
+
+def generator_forward_bf16(folded_t: Mapping[str, object], mel, cfg: Optional[OracleConfig] = None,
+                           taps: Optional[dict] = None, slope: float = LRELU_SLOPE):
+    """The generator with bf16 STORAGE (BASELINE.json configs[2]) restated on the CPU: same dataflow as
+    ``generator_forward_torch`` (reference src/iris/hifigan_pretrained.py:123-143), with a round-to-nearest-even
+    to bf16 wherever the MI355X bf16 path stores a value or feeds the matrix cores:
+      * weights (not biases) are rounded once;
+      * the input of every conv except conv_post is rounded after its activation (mel, LeakyReLU(x),
+        LeakyReLU(mean of the MRF branches));
+      * every conv output is rounded after bias (and residual) have been added in fp32;
+      * the MRF mean is ((y0 + y1) + y2) * fp32(1/3) in fp32; conv_post and tanh are fp32 on the unrounded
+        LeakyReLU of that mean.
+    Products are exact in fp32 (bf16 x bf16) and accumulated in fp32, as v_mfma_f32_32x32x16_bf16 does, up
+    to summation order.  The reference has no bf16 path: this function is the definition of the variant, and
+    its distance to the fp32 generator is what tests report ("bf16 tolerance unpinned by the reference").
+    mel [B, in_channels, T] -> [B, 1, hop*T] fp32 tensor."""
+    import torch
+    import torch.nn.functional as F
+
+    cfg = cfg or OracleConfig()
+
+    def r16(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def wq(name):
+        return r16(folded_t[name + ".weight"]), folded_t[name + ".bias"]
+
+    with torch.no_grad():
+        x = r16(torch.as_tensor(mel).float())
+        w, b = wq("conv_pre")
+        k = w.shape[-1]
+        x = r16(F.conv1d(x, w, b, padding=(k - 1) // 2))
+        if taps is not None:
+            taps["conv_pre"] = x
+        inv_n = torch.tensor(1.0 / cfg.num_kernels, dtype=torch.float32)
+        for i, (u, ku) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+            w, b = wq(f"ups.{i}")
+            x = r16(F.conv_transpose1d(r16(F.leaky_relu(x, slope)), w, b, stride=u, padding=(ku - u) // 2))
+            if taps is not None:
+                taps[f"ups.{i}"] = x
+            xs = None
+            for j in range(cfg.num_kernels):
+                p = f"resblocks.{i * cfg.num_kernels + j}"
+                r = x
+                for m, d in enumerate(cfg.resblock_dilation_sizes[j]):
+                    w1, b1 = wq(f"{p}.convs1.{m}")
+                    w2, b2 = wq(f"{p}.convs2.{m}")
+                    kk = w1.shape[-1]
+                    xt = r16(F.conv1d(r16(F.leaky_relu(r, slope)), w1, b1, dilation=d, padding=int((kk * d - d) / 2)))
+                    r = r16(F.conv1d(r16(F.leaky_relu(xt, slope)), w2, b2, padding=int((kk - 1) / 2)) + r)
+                xs = r if xs is None else xs + r
+            x = xs * inv_n                      # fp32, unrounded: rounded where the next conv stages it
             if taps is not None:
                 taps[f"mrf.{i}"] = x
         x = F.leaky_relu(x, slope)
