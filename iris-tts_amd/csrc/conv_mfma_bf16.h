@@ -21,7 +21,8 @@
 //                            the host-packed fragment order, prefetched four groups ahead in a register ring;
 //   B operand (activations): one ds_read_b128 per lane and (tap, 16 channels, 32 rows); LDS row stride
 //                            2*CIC + 16 bytes = 16 * odd -> conflict-free b128 reads and writes;
-//   D: lane = time step, registers 4g..4g+3 = 4 consecutive channels -> 8-byte bf16 stores.
+//   D: lane = time step, registers 4g..4g+3 = 4 consecutive channels; the epilogue turns each 32-row tile through
+//      a per-wave LDS scratch so that residual loads and bf16 stores are 16 bytes per lane and coalesced.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -73,6 +74,8 @@ struct Launch {
     int n_co_blk;         // blocks along C_out
     int Qp;               // padded number of 16-channel steps in the packed weights
     int n_ct;             // 32-wide C_out tiles in the packed weights
+    int ablate;           // diagnostics only (env IRIS_B16_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores,
+                          // 8 no residual loads.  Results are wrong.
 };
 
 // ---- small helpers -------------------------------------------------------------------------------
@@ -117,40 +120,59 @@ __device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, 
         const __amdgpu_buffer_rsrc_t r3 = make_rsrc((mrf && a.n_mrf > 3 ? a.xmrf[3] : a.xmrf[0]) + boff, mrf && a.n_mrf > 3 ? tensor_bytes : 0u);
         const int total = R * PPR;
         const float slope = a.in_act == IN_ACT_NONE ? 1.f : a.slope;
-        constexpr int U = 4;              // pieces in flight per thread
-        for (int base = 0; base < total; base += 256 * U) {
-            u32x4 v0[U], v1[U], v2[U], v3[U];
-            int ldso[U];
+        auto piece = [&](int idx, unsigned& voff, int& ldso) {
+            const int r = idx / PPR, pc = idx - r * PPR;
+            const int row = in_row0 + r, ci = c0 + 8 * pc;
+            const bool ok = idx < total && row >= 0 && row < L_in && ci < C_in;
+            voff = (ok && !(a.ablate & 1)) ? (unsigned)(row * C_in + ci) * 2u : kOob;
+            ldso = idx < total ? r * SB + pc * 16 : -1;
+        };
+        if (!mrf) {
+            constexpr int U = 4;          // 16-byte pieces in flight per thread
+            for (int base = 0; base < total; base += 256 * U) {
+                u32x4 v0[U];
+                int ldso[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = base + u * 256 + tid;
-                const int r = idx / PPR, pc = idx - r * PPR;
-                const int row = in_row0 + r, ci = c0 + 8 * pc;
-                const bool ok = idx < total && row >= 0 && row < L_in && ci < C_in;
-                const unsigned voff = ok ? (unsigned)(row * C_in + ci) * 2u : kOob;
-                ldso[u] = idx < total ? r * SB + pc * 16 : -1;
-                v0[u] = buf_load4(r0, voff, 0);
-                if (mrf) {
+                for (int u = 0; u < U; ++u) {
+                    unsigned voff;
+                    piece(base + u * 256 + tid, voff, ldso[u]);
+                    v0[u] = buf_load4(r0, voff, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = pack_bf2(lrelu1(bf_lo(v0[u][e]), slope), lrelu1(bf_hi(v0[u][e]), slope));
+                    if (ldso[u] >= 0) *reinterpret_cast<u32x4*>(lds + ldso[u]) = o;
+                }
+            }
+        } else {
+            constexpr int U = 2;
+            for (int base = 0; base < total; base += 256 * U) {
+                u32x4 v0[U], v1[U], v2[U], v3[U];
+                int ldso[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    unsigned voff;
+                    piece(base + u * 256 + tid, voff, ldso[u]);
+                    v0[u] = buf_load4(r0, voff, 0);
                     v1[u] = buf_load4(r1, voff, 0);
                     v2[u] = buf_load4(r2, voff, 0);
                     v3[u] = buf_load4(r3, voff, 0);
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                u32x4 o;
+                for (int u = 0; u < U; ++u) {
+                    u32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo = bf_lo(v0[u][e]), hi = bf_hi(v0[u][e]);
-                    if (mrf) {
-                        lo += bf_lo(v1[u][e]); hi += bf_hi(v1[u][e]);
-                        lo += bf_lo(v2[u][e]); hi += bf_hi(v2[u][e]);
-                        if (a.n_mrf > 3) { lo += bf_lo(v3[u][e]); hi += bf_hi(v3[u][e]); }
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = ((bf_lo(v0[u][e]) + bf_lo(v1[u][e])) + bf_lo(v2[u][e])) + bf_lo(v3[u][e]);
+                        float hi = ((bf_hi(v0[u][e]) + bf_hi(v1[u][e])) + bf_hi(v2[u][e])) + bf_hi(v3[u][e]);
                         lo *= a.inv_n_mrf; hi *= a.inv_n_mrf;
+                        o[e] = pack_bf2(lrelu1(lo, slope), lrelu1(hi, slope));
                     }
-                    o[e] = pack_bf2(lrelu1(lo, slope), lrelu1(hi, slope));
+                    if (ldso[u] >= 0) *reinterpret_cast<u32x4*>(lds + ldso[u]) = o;
                 }
-                if (ldso[u] >= 0) *reinterpret_cast<u32x4*>(lds + ldso[u]) = o;
             }
         }
     } else {
@@ -196,10 +218,14 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const char* a_l
         for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const u32x4*>(ap + m * 32 * SB);
     };
     u32x4 wv[D][NT], av[2][MT];
+    // (issue order pinned: vmcnt is in-order, so slot 0 must be the OLDEST request when the loop is entered --
+    //  hipcc otherwise loads it last and the loop head waits for vmcnt(0) on every iteration)
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int i = 0; i < D; ++i) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(i));
+        __builtin_amdgcn_sched_barrier(0);
+    }
     load_a(av[0], 0);
     for (int n0 = 0; n0 < NG; n0 += D) {
 #pragma unroll
@@ -223,8 +249,8 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const char* a_l
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------
-template <int WT, int WC, int MT, int NT, int CIC>
-__global__ void __launch_bounds__(256, 2) conv_mfma_bf16_kernel(const Launch a) {
+template <int WT, int WC, int MT, int NT, int CIC, int MINB>
+__global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch a) {
     extern __shared__ __attribute__((aligned(16))) char lds_b16[];
     char* lds = lds_b16;
     constexpr int SB = CIC * 2 + 16;
@@ -273,64 +299,93 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_bf16_kernel(const Launch a) 
         if (c0 > 0) __syncthreads();
         stage_window<CIC>(a, p, lds, b, in_row0, R, c0);
         __syncthreads();
-        if (wave_active)
+        if (wave_active && !(a.ablate & 2))
             mma_chunk<MT, NT, CIC>(acc, a_lane, dil_bytes, wr, wvoff, q_bytes, tap_bytes,
                                    (unsigned)(c0 >> 4) * q_bytes, ks);
     }
+    // Epilogue.  In the D = W x X^T layout a lane owns 4 channels of one row: storing from there would be 8-byte
+    // pieces 2*C bytes apart (measured: a third of the kernel).  Each wave therefore turns its 32-row m-tiles
+    // through a private LDS scratch (fp32, bias added, [row][channel]) and reads them back as 16-byte bf16
+    // pieces that are contiguous in the channels-last row: residual loads and stores are fully coalesced.
+    // (acc + bias) + residual is formed in fp32 and rounded to bf16 once.  The scratch aliases the input
+    // window, so every wave must be done with the window first.
+    __syncthreads();
     if (!wave_active) return;
-
-    // Epilogue: bias + residual in fp32, one rounding to bf16, 8-byte stores (4 channels of one row).
+    constexpr int RS = NT * 32 * 4 + 16;               // scratch row stride (bytes) = 16 * odd
+    constexpr int PPRO = NT * 4;                       // 16-byte bf16 pieces per row of this wave's channel span
+    constexpr int NP = 2 * NT;                         // pieces per lane and m-tile
+    char* scr = lds + wave * (32 * RS);
     const unsigned out_bytes = (unsigned)a.L_out * (unsigned)a.C_out * 2u;
     const size_t ob = (size_t)b * a.L_out * a.C_out;
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + ob, out_bytes);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, p.res ? out_bytes : 0u);
-    unsigned voff[MT];
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, (p.res && !(a.ablate & 8)) ? out_bytes : 0u);
+    // this lane's pieces of an m-tile: q = j*64 + lane -> row q / PPRO, channels 8*(q % PPRO) .. +7 of the span
+    unsigned pvoff[MT][NP];
+    int pscr[NP];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int im = i0 + (wt * MT + m) * 32 + lo;
-        const int o = im * a.out_stride + out_off;
-        const bool ok = im < a.n_idx && o >= 0 && o < a.L_out;
-        voff[m] = ok ? (unsigned)(o * a.C_out + 4 * hi) * 2u : kOob;
+    for (int j = 0; j < NP; ++j) {
+        const int q = j * 64 + lane;
+        const int row_l = q / PPRO, pc = q - row_l * PPRO;
+        pscr[j] = row_l * RS + pc * 32;
+        const int co = ct0 * 32 + 8 * pc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int im = i0 + (wt * MT + m) * 32 + row_l;
+            const int o = im * a.out_stride + out_off;
+            const bool ok = im < a.n_idx && o >= 0 && o < a.L_out && co < a.C_out;
+            pvoff[m][j] = ok ? (unsigned)(o * a.C_out + co) * 2u : kOob;
+        }
     }
-    u32x2 outp[MT][NT][4];
+    u32x4 resv[MT][NP];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) resv[m][j] = buf_load4(rr, pvoff[m][j], 0);
+    f32x4 bias4[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (co < a.C_out) bias4 = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x2 rv = buf_load2(rr, co < a.C_out ? voff[m] : kOob, (unsigned)((ct0 + nt) * 32 + 8 * g) * 2u);
-                const float v0 = (acc[m][nt][4 * g + 0] + bias4[0]) + bf_lo(rv[0]);
-                const float v1 = (acc[m][nt][4 * g + 1] + bias4[1]) + bf_hi(rv[0]);
-                const float v2 = (acc[m][nt][4 * g + 2] + bias4[2]) + bf_lo(rv[1]);
-                const float v3 = (acc[m][nt][4 * g + 3] + bias4[3]) + bf_hi(rv[1]);
-                outp[m][nt][g][0] = pack_bf2(v0, v1);
-                outp[m][nt][g][1] = pack_bf2(v2, v3);
-            }
+            bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (co < a.C_out ? co : 0));
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
-                buf_store2(outp[m][nt][g], yr, co < a.C_out ? voff[m] : kOob, (unsigned)((ct0 + nt) * 32 + 8 * g) * 2u);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e] + bias4[nt][g][e];
+                *reinterpret_cast<f32x4*>(scr + lo * RS + (nt * 32 + 8 * g + 4 * hi) * 4) = v;
             }
-    __builtin_amdgcn_sched_barrier(0);
-    // the store data must stay live until every store has issued (see the store-data note in
-    // mrf_conv_mfma_f32.h: hipcc otherwise re-uses a store's data VGPRs right behind it)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 outp[NP];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int j = 0; j < NP; ++j) {
+            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(scr + pscr[j]);
+            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + pscr[j] + 16);
+            const u32x4 rv = resv[m][j];
+            outp[j][0] = pack_bf2(lo4[0] + bf_lo(rv[0]), lo4[1] + bf_hi(rv[0]));
+            outp[j][1] = pack_bf2(lo4[2] + bf_lo(rv[1]), lo4[3] + bf_hi(rv[1]));
+            outp[j][2] = pack_bf2(hi4[0] + bf_lo(rv[2]), hi4[1] + bf_hi(rv[2]));
+            outp[j][3] = pack_bf2(hi4[2] + bf_lo(rv[3]), hi4[3] + bf_hi(rv[3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int j = 0; j < NP; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pvoff[m][j]), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the store data must stay live until every store of the group has issued (see the store-data note in
+        // mrf_conv_mfma_f32.h: hipcc otherwise re-uses a store's data VGPRs right behind it)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(outp[m][nt][g]));
+        for (int j = 0; j < NP; ++j) asm volatile("" :: "v"(outp[j]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the scratch is rewritten by the next m-tile
+    }
 }
 
 // ---- conv_post for bf16 inputs (hifigan_pretrained.py:139-141): fp32 sliding dot product --------------
@@ -461,14 +516,27 @@ inline void pack_convt_bf16(const float* w, int C_in, int C_out, int k, int u, u
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
-struct Tile { int WT, WC, MT, NT, CIC, T_BLK, CO_BLK; };
+struct Tile { int WT, WC, MT, NT, CIC, MINB, T_BLK, CO_BLK; };
+
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 inline Tile pick_tile(int C_in, int C_out) {
+    static const int v32 = env_int("IRIS_B16_TILE32", 0), v64 = env_int("IRIS_B16_TILE64", 0), v128 = env_int("IRIS_B16_TILE128", 0);
     Tile t;
-    if (C_out <= 32)      { t.WT = 4; t.WC = 1; t.MT = 4; t.NT = 1; }
-    else if (C_out <= 64) { t.WT = 4; t.WC = 1; t.MT = 2; t.NT = 2; }
-    else                  { t.WT = 2; t.WC = 2; t.MT = 2; t.NT = 2; }
-    t.CIC = (C_in <= 32) ? 32 : 64;
+    if (C_out <= 32) {
+        t.WT = 4; t.WC = 1; t.NT = 1;
+        t.MT = (v32 & 1) ? 2 : 4;
+        t.MINB = 2 + (v32 >> 1);          // v32: bit0 -> MT=2, bits1.. -> min blocks 2/3/4
+    } else if (C_out <= 64) {
+        t.WT = 4; t.WC = 1; t.NT = 2;
+        t.MT = (v64 & 1) ? 1 : 2;
+        t.MINB = 2 + (v64 >> 1);
+    } else {
+        t.WT = 2; t.WC = 2; t.NT = 2;
+        t.MT = (v128 & 1) ? 4 : 2;
+        t.MINB = 2;
+    }
+    t.CIC = (C_in <= 32 && t.NT == 1) ? 32 : 64;
     t.T_BLK = t.WT * t.MT * 32;
     t.CO_BLK = t.WC * t.NT * 32;
     return t;
@@ -482,6 +550,8 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     a.n_ct = packed_cotiles(a.C_out);
     a.nz = nz;
     a.inv_n_mrf = a.n_mrf > 0 ? 1.0f / (float)a.n_mrf : 1.0f;
+    static const int ablate_env = env_int("IRIS_B16_ABLATE", 0);
+    a.ablate = ablate_env;
     int span = 0;
     const int np = a.z_is_phase ? 1 : nz;
     if (np > kMaxGroup) return hipErrorInvalidValue;
@@ -494,7 +564,9 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
         return hipErrorInvalidValue;
     if (!a.x_f32_cf && (a.C_in & 7)) return hipErrorInvalidValue;
     if (a.C_out & 3) return hipErrorInvalidValue;
-    const size_t lds_bytes = (size_t)(t.T_BLK + span) * (t.CIC * 2 + 16);
+    const size_t window_bytes = (size_t)(t.T_BLK + span) * (t.CIC * 2 + 16);
+    const size_t scratch_bytes = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);      // epilogue transpose, aliases the window
+    const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
     dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
@@ -508,13 +580,21 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
             if (e != hipSuccess) return e;                                                        \
         }                                                                                         \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+        return hipGetLastError();                                                                 \
     } while (0)
-    if (t.NT == 1 && t.CIC == 32)      IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 4, 1, 32>);
-    else if (t.NT == 1)                IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 4, 1, 64>);
-    else if (t.WC == 1)                IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<4, 1, 2, 2, 64>);
-    else                               IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<2, 2, 2, 2, 64>);
+#define IRIS_B16_CASE(WT_, WC_, MT_, NT_, CIC_, MINB_)                                            \
+    if (t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.CIC == CIC_ && t.MINB == MINB_) \
+        IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<WT_, WC_, MT_, NT_, CIC_, MINB_>)
+    IRIS_B16_CASE(4, 1, 4, 1, 32, 2); IRIS_B16_CASE(4, 1, 4, 1, 32, 3); IRIS_B16_CASE(4, 1, 4, 1, 32, 4);
+    IRIS_B16_CASE(4, 1, 2, 1, 32, 2); IRIS_B16_CASE(4, 1, 2, 1, 32, 3); IRIS_B16_CASE(4, 1, 2, 1, 32, 4);
+    IRIS_B16_CASE(4, 1, 4, 1, 64, 2); IRIS_B16_CASE(4, 1, 4, 1, 64, 3); IRIS_B16_CASE(4, 1, 4, 1, 64, 4);
+    IRIS_B16_CASE(4, 1, 2, 1, 64, 2); IRIS_B16_CASE(4, 1, 2, 1, 64, 3); IRIS_B16_CASE(4, 1, 2, 1, 64, 4);
+    IRIS_B16_CASE(4, 1, 2, 2, 64, 2); IRIS_B16_CASE(4, 1, 2, 2, 64, 3); IRIS_B16_CASE(4, 1, 2, 2, 64, 4);
+    IRIS_B16_CASE(4, 1, 1, 2, 64, 2); IRIS_B16_CASE(4, 1, 1, 2, 64, 3); IRIS_B16_CASE(4, 1, 1, 2, 64, 4);
+    IRIS_B16_CASE(2, 2, 2, 2, 64, 2); IRIS_B16_CASE(2, 2, 4, 2, 64, 2);
+#undef IRIS_B16_CASE
 #undef IRIS_B16_LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace b16
