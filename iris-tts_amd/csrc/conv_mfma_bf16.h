@@ -74,6 +74,8 @@ struct Launch {
     int n_co_blk;         // blocks along C_out
     int Qp;               // padded number of 16-channel steps in the packed weights
     int n_ct;             // 32-wide C_out tiles in the packed weights
+    int n_items;          // time tiles x nz
+    int xcd_group;        // C_out blocks of one window share an XCD (see the kernel)
     int ablate;           // diagnostics only (env IRIS_B16_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores,
                           // 8 no residual loads.  Results are wrong.
 };
@@ -202,10 +204,11 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const char* a_l
                                           __amdgpu_buffer_rsrc_t wr, unsigned wvoff, unsigned q_bytes,
                                           unsigned tap_bytes, unsigned q0_bytes, int ks) {
     constexpr int QPC = CIC / 16;
-    constexpr int QL = QPC == 4 ? 2 : (QPC == 2 ? 1 : 0);
-    static_assert(QPC == 4 || QPC == 2 || QPC == 1, "CIC must be 16, 32 or 64");
+    constexpr int QL = QPC == 8 ? 3 : (QPC == 4 ? 2 : (QPC == 2 ? 1 : 0));
+    static_assert(QPC == 8 || QPC == 4 || QPC == 2 || QPC == 1, "CIC must be 16, 32, 64 or 128");
     constexpr int SB = CIC * 2 + 16;
-    constexpr int D = 4;
+    // ring depth: a group of 8 MFMAs lasts 256 cycles, two of them cover an L2 hit (and ks*2 groups need no tail)
+    constexpr int D = (QPC == 2 && MT * NT >= 8) ? 2 : 4;
     const int NG = ks * QPC;
     auto w_soff = [&](int n) -> unsigned {
         return (unsigned)(n >> QL) * tap_bytes + q0_bytes + (unsigned)(n & (QPC - 1)) * q_bytes;
@@ -260,7 +263,23 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     const int lo = lane & 31, hi = lane >> 5;
 
     // z = MRF branch (heaviest first) or ConvTranspose phase; compile-time indices keep the kernarg in SGPRs
-    const int zr = blockIdx.x % a.nz;
+    // blockIdx.x -> (row-work item r = tile_t * nz + z, C_out block).  With several C_out blocks the blocks that
+    // share an input window are given the same XCD (blockIdx.x % 8) and neighbouring slots, so the window is
+    // fetched from HBM once and re-read from that XCD's L2.
+    int r_item, tile_co;
+    if (a.xcd_group) {
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+        tile_co = s % a.n_co_blk;
+        r_item = (s / a.n_co_blk) * 8 + xcd;
+        if (r_item >= a.n_items) return;
+    } else if (a.n_co_blk > 1) {
+        tile_co = blockIdx.x % a.n_co_blk;
+        r_item = blockIdx.x / a.n_co_blk;
+    } else {
+        tile_co = 0;
+        r_item = blockIdx.x;
+    }
+    const int zr = r_item % a.nz;
     const int z = a.z_is_phase ? zr : a.nz - 1 - zr;
     const int pz = a.z_is_phase ? 0 : z;
     Problem p = a.p[0];
@@ -269,8 +288,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     if (pz == 3) p = a.p[3];
     const int out_off = a.out_off + (a.z_is_phase ? z : 0);
 
-    const int bid = blockIdx.x / a.nz;
-    const int tile_co = bid % a.n_co_blk, tile_t = bid / a.n_co_blk;
+    const int tile_t = r_item / a.nz;
     const int b = blockIdx.y;
     const int i0 = tile_t * T_BLK;
     const int ks = p.ks;
@@ -533,10 +551,12 @@ inline Tile pick_tile(int C_in, int C_out) {
         t.MINB = 2 + (v64 >> 1);
     } else {
         t.WT = 2; t.WC = 2; t.NT = 2;
-        t.MT = (v128 & 1) ? 4 : 2;
+        t.MT = 2;
         t.MINB = 2;
     }
     t.CIC = (C_in <= 32 && t.NT == 1) ? 32 : 64;
+    // wide layers: 128-channel chunks halve the staging round trips of a block (window 48 KB, three blocks per CU)
+    if (C_out > 64 && !(v128 & 2) && C_in % 128 == 0) t.CIC = 128;
     t.T_BLK = t.WT * t.MT * 32;
     t.CO_BLK = t.WC * t.NT * 32;
     return t;
@@ -569,7 +589,10 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
-    dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
+    a.n_items = n_t * nz;
+    a.xcd_group = a.n_co_blk > 1 && a.n_items >= 64;      // (a few items would leave XCDs without work)
+    const int gx = a.xcd_group ? ((a.n_items + 7) / 8) * 8 * a.n_co_blk : a.n_items * a.n_co_blk;
+    dim3 grid((unsigned)gx, (unsigned)a.B, 1u), block(256);
 #define IRIS_B16_LAUNCH(...)                                                                      \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
@@ -591,7 +614,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     IRIS_B16_CASE(4, 1, 2, 1, 64, 2); IRIS_B16_CASE(4, 1, 2, 1, 64, 3); IRIS_B16_CASE(4, 1, 2, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 2, 64, 2); IRIS_B16_CASE(4, 1, 2, 2, 64, 3); IRIS_B16_CASE(4, 1, 2, 2, 64, 4);
     IRIS_B16_CASE(4, 1, 1, 2, 64, 2); IRIS_B16_CASE(4, 1, 1, 2, 64, 3); IRIS_B16_CASE(4, 1, 1, 2, 64, 4);
-    IRIS_B16_CASE(2, 2, 2, 2, 64, 2); IRIS_B16_CASE(2, 2, 4, 2, 64, 2);
+    IRIS_B16_CASE(2, 2, 2, 2, 64, 2); IRIS_B16_CASE(2, 2, 2, 2, 128, 2);
 #undef IRIS_B16_CASE
 #undef IRIS_B16_LAUNCH
     return hipErrorInvalidValue;

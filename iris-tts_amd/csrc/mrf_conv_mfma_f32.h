@@ -127,8 +127,10 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         if (ci >= C || (ablate & 1)) return kOobOffset;
         return (unsigned)((in_row0 + r_lane) * C + ci) * 4u;
     };
-    auto stage_load_one = [&](int i, __amdgpu_buffer_rsrc_t xr, unsigned vbase) {
-        st[i] = buf_load4(xr, vbase + (unsigned)i * row_stride, 0);
+    auto stage_load_one = [&](int i, __amdgpu_buffer_rsrc_t xr, unsigned vbase, int R) {
+        // rows past this branch's window (R < T_BLK + kMrfSpanMax for the short kernels) are not requested:
+        // they would be real rows of the tensor, i.e. HBM reads that nobody uses
+        st[i] = buf_load4(xr, r_lane + i * RPI < R ? vbase + (unsigned)i * row_stride : kOobOffset, 0);
     };
     auto stage_write_all = [&](int R) {      // LeakyReLU on the way in (hifigan_pretrained.py:66,68)
 #pragma unroll
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #pragma unroll
             for (int n = 0; n < NG; ++n) {
                 if (!(ablate & 16)) {
-                    if (n < NQ) stage_load_one(n, xrn, vbn_eff);
+                    if (n < NQ) stage_load_one(n, xrn, vbn_eff, Rn);
 #pragma unroll
                     for (int j = 0; j < RPG; ++j)
                         if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn_eff);
+            for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn_eff, Rn);
             IRIS_STAMP(ts1);
             IRIS_SEG(0, ts0, ts1);
             // the next phase expects its groups 0..DB-1 in ring slots 0..DB-1: they were loaded into
@@ -375,7 +377,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         const __amdgpu_buffer_rsrc_t wr0 = make_rsrc(p0.wp, (unsigned)(p0.ks * a.Gp) * wbytes_group);
         const unsigned vb0 = stage_vbase(t.i0 - p0.pad_left, 0);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) stage_load_one(i, xr0, vb0);
+        for (int i = 0; i < NQ; ++i) stage_load_one(i, xr0, vb0, R0);
 #pragma unroll
         for (int d = 0; d < DB; ++d) bw[d] = buf_load4(wr0, t.wvoff, (unsigned)d * wbytes_group);
         stage_write_all(R0);
