@@ -39,13 +39,19 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0 # dense, same table
 PEAK_HBM_GBS = 8000.0          # spec; 6.3 TB/s achievable
 
 
-def committed_traffic(batch, frames):
+def committed_traffic(batch, frames, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 correction applied:
-    profiles/r*_hbm_traffic.json).  PMC counters cannot be collected from inside this process, so the
-    figure is the committed measurement of the same workload, or None when the workload differs."""
-    files = sorted((REPO / "profiles").glob("r*_hbm_traffic.json"))
-    if not files or (batch, frames) != (1, 1000):
+    profiles/r*_hbm_traffic.json, produced by tools/hbm_traffic.sh).  PMC counters cannot be collected from
+    inside this process, so the figure is the committed measurement of the same workload, or None when the
+    workload differs."""
+    if (dtype, batch, frames) == ("f32", 1, 1000):
+        files = [f for f in sorted((REPO / "profiles").glob("r*_hbm_traffic.json")) if "bf16" not in f.name]
+    elif (dtype, batch, frames) == ("bf16", 32, 500):
+        files = sorted((REPO / "profiles").glob("r*_bf16_c3_hbm_traffic.json"))
+    else:
+        files = []
+    if not files:
         return None
     try:
         return json.loads(files[-1].read_text())["mrf_traffic_bytes_per_launch"]
@@ -203,7 +209,7 @@ def main():
             # (FLOP / 2.5 PFLOP/s) -- 235 FLOP/B against a machine balance of 312 -- so HBM is the binding roof
             roofline = {"kernel": "conv_mfma_bf16_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
                         "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "frac": gbs / PEAK_HBM_GBS, "traffic": committed_traffic(B, T, "bf16"),
                         "avg_launch_ms": dom["ms"] / dom["n"], "bytes_per_launch": dom["bytes"] / dom["n"],
                         "flop_per_launch": dom["flops"] / dom["n"],
                         "mfma_achieved_tflops": achieved, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,

@@ -8,6 +8,7 @@ This object replaces ``self.model(mel_tensor)`` of the reference
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Mapping, Optional
 
 import numpy as np
@@ -39,7 +40,11 @@ class GeneratorEngine:
     """One HiFiGAN generator resident on one GPU."""
 
     def __init__(self, cfg: GeneratorConfig, state_dict: Mapping[str, object],
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, dtype: Optional[str] = None):
+        # default arithmetic of forward(): "f32" unless the caller or IRIS_VOCODER_DTYPE says "bf16" (the drop-in
+        # wrappers construct engines without a dtype, so the environment variable switches them too)
+        self.default_dtype = dtype or os.environ.get("IRIS_VOCODER_DTYPE", "f32")
+        _dtype_code(self.default_dtype)
         self.cfg = cfg
         self.lib = _native.load()
         self.device = device if device is not None else require_gpu()
@@ -74,7 +79,8 @@ class GeneratorEngine:
             pass
 
     # -- forward -----------------------------------------------------------------------------
-    def workspace_bytes(self, batch: int, frames: int, dtype: str = "f32") -> int:
+    def workspace_bytes(self, batch: int, frames: int, dtype: Optional[str] = None) -> int:
+        dtype = dtype or self.default_dtype
         n = ctypes.c_uint64()
         _native.check("iris_hifigan_workspace_bytes", self.lib.iris_hifigan_workspace_bytes(
             self._handle, batch, frames, _dtype_code(dtype), ctypes.byref(n)))
@@ -86,11 +92,12 @@ class GeneratorEngine:
             self._workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: str = "f32") -> torch.Tensor:
+    def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: Optional[str] = None) -> torch.Tensor:
         """mel: fp32 device tensor [B, in_channels, T] -> waveform fp32 [B, hop*T] (asynchronous on
         the current stream).  ``dtype`` selects the storage/arithmetic of the layers in between: "f32" (the
         parity path, <= 1e-4 against the reference) or "bf16" (bf16 activations and weights, fp32
-        accumulation; BASELINE.json configs[2])."""
+        accumulation; BASELINE.json configs[2]); None = the engine's default_dtype."""
+        dtype = dtype or self.default_dtype
         code = _dtype_code(dtype)
         if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
             raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
@@ -116,13 +123,14 @@ class GeneratorEngine:
     __call__ = forward
 
     # -- hipGraph replay ---------------------------------------------------------------------------
-    def forward_graph(self, mel: torch.Tensor, dtype: str = "f32") -> torch.Tensor:
+    def forward_graph(self, mel: torch.Tensor, dtype: Optional[str] = None) -> torch.Tensor:
         """Same result as ``forward`` but the launches of one forward are captured once per
         (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 30
         kernel launches, and the inter-kernel gaps shrink to the graph's own.  ``iris_hifigan_forward`` is
         capture-safe by construction (no allocation, no synchronisation, caller's stream).  The returned
         tensor is the graph's static output buffer: it is overwritten by the next replay of the same shape.
         Per-launch profiling records are not produced in this mode."""
+        dtype = dtype or self.default_dtype
         if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
             raise ValueError(f"expected mel [B, {self.cfg.in_channels}, T], got {tuple(mel.shape)}")
         batch, _, frames = mel.shape

@@ -207,3 +207,23 @@ def test_bf16_hipgraph_replay_matches_eager(engine, dev):
     eager = eng.forward(mel, dtype="bf16").clone()
     assert torch.equal(eng.forward_graph(mel, dtype="bf16"), eager)
     assert torch.equal(eng.forward_graph(mel, dtype="bf16"), eager)
+
+
+def test_default_dtype_switch(engine, dev, monkeypatch):
+    """IRIS_VOCODER_DTYPE / GeneratorEngine(dtype=...) select what forward() computes in when no dtype is passed:
+    that is how the drop-in wrappers (which know nothing about dtypes) are switched to bf16."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import seeded_mel
+    eng, sd = engine
+    mel = torch.from_numpy(seeded_mel(3, 1, 30)).to(dev)
+    want16 = eng.forward(mel, dtype="bf16").clone()
+    want32 = eng.forward(mel).clone()
+    assert not torch.equal(want16, want32)
+    monkeypatch.setenv("IRIS_VOCODER_DTYPE", "bf16")
+    e2 = GeneratorEngine(eng.cfg, sd, dev)
+    assert e2.default_dtype == "bf16" and torch.equal(e2.forward(mel), want16)
+    assert torch.equal(e2.forward(mel, dtype="f32"), want32)
+    e2.close()
+    monkeypatch.setenv("IRIS_VOCODER_DTYPE", "int4")
+    with pytest.raises(ValueError):
+        GeneratorEngine(eng.cfg, sd, dev)

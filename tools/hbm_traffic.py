@@ -16,12 +16,14 @@ n = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 fetch, write = load(sys.argv[1], "FETCH_SIZE")[-n:], load(sys.argv[2], "WRITE_SIZE")[-n:]
 assert len(fetch) == len(write) == n, (len(fetch), len(write))
 rows, mrf = [], []
-for (kn, grid, f), (kn2, _, w) in zip(fetch, write):
+# launch plan of one forward (iris_hifigan.hip): conv_pre, 4 x (upsample, 6 MRF steps), conv_post
+mrf_pos = {i for i in range(n) if n == 30 and 1 <= i <= 28 and (i - 1) % 7 != 0}
+for pos, ((kn, grid, f), (kn2, _, w)) in enumerate(zip(fetch, write)):
     assert kn == kn2
     name = kn.split("(")[0].replace("void iris::", "").replace("b16::", "b16::")
     t = 2.0 * f * 1024.0 + w * 1024.0
     rows.append({"kernel": name, "grid": grid, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "traffic_bytes_corrected": t})
-    if name.startswith("mrf_conv") or (name.startswith("b16::conv_mfma_bf16") and False):
+    if pos in mrf_pos:
         mrf.append(t)
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes); last forward (%d dispatches)" % n,
        "correction": "gfx950: read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 exact (MI355X_MICROARCH.md, HBM)",
