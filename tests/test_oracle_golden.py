@@ -90,3 +90,26 @@ def test_wrapper_shape_rules_match_reference(manifest):
         for entry in ("generator_call", "infer_hifigan"):
             assert list(orc.wrapper_shapes(entry, shape)) == per_entry[entry]["shape"]
             assert per_entry[entry]["dtype"] == "float32"
+
+
+def test_bf16_restatement_stays_close_to_the_pinned_fp32_oracle():
+    """``generator_forward_bf16`` defines the bf16-storage variant (parity unpinned by the reference): its rounding
+    points must not move it further from the pinned fp32 restatement than bf16 storage noise."""
+    import torch
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    folded = orc.to_torch_folded(sd)
+    mel = seeded_mel(5, 2, 24, log_mel=True)
+    taps16, taps32 = {}, {}
+    w16 = orc.generator_forward_bf16(folded, mel, taps=taps16).numpy()
+    w32 = orc.generator_forward_torch(folded, mel, taps=taps32).numpy()
+    assert w16.shape == w32.shape == (2, 1, 24 * 256)
+    d = np.abs(w16 - w32)
+    assert d.max() <= 6e-2 and d.mean() <= 5e-3 and d.max() > 1e-5          # close, but really rounded
+    # stored tensors hold bf16 values only
+    for name in ("conv_pre", "ups.0", "ups.3"):
+        t = taps16[name]
+        assert torch.equal(t, t.to(torch.bfloat16).to(torch.float32))
+        rel = (t - taps32[name]).abs().max() / taps32[name].abs().max()
+        assert rel < 5e-2

@@ -38,7 +38,7 @@ def test_chunked_oracle_equals_one_shot():
     full = fwd(mel)
     chunked = StreamingVocoder(fwd, chunk_frames=16).infer(mel)
     assert chunked.shape == full.shape
-    assert np.abs(chunked - full).max() <= 2e-6
+    assert np.abs(chunked - full).max() <= 2e-5      # fp32 rounding only (ATen picks kernels by length and thread count)
     # and a halo that is too small is visibly wrong at the seams (the check above is not vacuous)
     bad = np.concatenate([fwd(mel[:, :, max(0, s - 4):min(70, s + 16 + 4)])[:, (s - max(0, s - 4)) * 256:][:, :256 * min(16, 70 - s)]
                           for s in range(0, 70, 16)], axis=1)
