@@ -227,3 +227,34 @@ def test_default_dtype_switch(engine, dev, monkeypatch):
     monkeypatch.setenv("IRIS_VOCODER_DTYPE", "int4")
     with pytest.raises(ValueError):
         GeneratorEngine(eng.cfg, sd, dev)
+
+
+def test_bf16_generic_config_and_unsupported_config(dev, case_setup):
+    """A non-V1 generator (2 MRF kernels of sizes 3/5, rates 4/2/3, channels 64 -> 32/16/8) runs through the same
+    bf16 kernels; one whose channel counts are not multiples of 8 is refused with UNSUPPORTED, not mis-computed."""
+    from conftest import oracle_config
+    from iris import _native
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig(in_channels=16, upsample_rates=(4, 2, 3), upsample_kernel_sizes=(8, 4, 9),
+                          upsample_initial_channel=64, resblock_kernel_sizes=(3, 5),
+                          resblock_dilation_sizes=((1, 2), (2, 6)))
+    sd = seeded_state_dict(cfg, seed=7, gain=1.3, post_gain=6.0)
+    eng = GeneratorEngine(cfg, sd, dev)
+    rng = np.random.default_rng(3)
+    mel = rng.standard_normal((3, 16, 37)).astype(np.float32)
+    got = eng.forward(torch.from_numpy(mel).to(dev), dtype="bf16").cpu().numpy()
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel, oracle_config(cfg)).numpy()[:, 0, :]
+    assert got.shape == want.shape == (3, 37 * 24)
+    d = np.abs(got - want)
+    assert np.isfinite(got).all() and d.max() <= TOL_BF16_MAX and d.mean() <= TOL_BF16_MEAN
+    assert np.abs(eng.forward(torch.from_numpy(mel).to(dev), dtype="f32").cpu().numpy() - want).max() <= 1e-4
+    eng.close()
+
+    cfg2, sd2 = case_setup("small_cfg_B3_T19")      # channels 48 -> 24 / 12 / 6
+    eng2 = GeneratorEngine(cfg2, sd2, dev)
+    with pytest.raises(_native.NativeCallError) as exc:
+        eng2.forward(torch.zeros((1, cfg2.in_channels, 5), device=dev), dtype="bf16")
+    assert "multiples of 8" in str(exc.value)
+    assert eng2.forward(torch.zeros((1, cfg2.in_channels, 5), device=dev)).shape == (1, 5 * cfg2.hop_length)
+    eng2.close()
