@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
                     "roofline is then null; the default eager mode is the measured configuration)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collective "
+                    "path (barrier, all-gather, max-reduce) even with one rank: exercises the RCCL code path of N > 1 "
+                    "on a one-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
                     "gloo only for rehearsing the control flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -125,8 +128,10 @@ def main():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} HIP device(s): RCCL needs one GPU per rank")
     dev = torch.device("cuda", local_rank % n_dev)     # (ranks share a GPU only in a gloo rehearsal)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -139,19 +144,19 @@ def main():
     eng = GeneratorEngine(cfg, sd, dev)
     mel = torch.from_numpy(mel_np).to(dev)
     wav = torch.empty((B, T * eng.hop_length), dtype=torch.float32, device=dev)
-    gathered = torch.empty((B * world, T * eng.hop_length), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((B * world, T * eng.hop_length), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         if args.graph:
             out = eng.forward_graph(mel, dtype=args.dtype)
         else:
             out = eng.forward(mel, out=wav, dtype=args.dtype)
-        if world > 1:
+        if use_dist:
             gather_waveforms(out, B * world, out=gathered)
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -167,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     recs = eng.read_profile() if profile else []
     eng.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -217,7 +222,7 @@ def main():
                         "share_of_step": dom["ms"] / args.steps / ms_per_step}
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -247,7 +252,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
