@@ -77,7 +77,7 @@ struct Launch {
     int n_items;          // time tiles x nz
     int xcd_group;        // C_out blocks of one window share an XCD (see the kernel)
     int ablate;           // diagnostics only (env IRIS_B16_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores,
-                          // 8 no residual loads.  Results are wrong.
+                          // 8 no residual loads, 16 every weight fragment from one (L1-resident) address.  Results are wrong.
 };
 
 // ---- small helpers -------------------------------------------------------------------------------
@@ -305,10 +305,10 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
 
-    const unsigned q_bytes = (unsigned)a.n_ct * 1024u;           // bytes per (tap, 16-channel step)
-    const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
+    const unsigned q_bytes = (a.ablate & 16) ? 0u : (unsigned)a.n_ct * 1024u;   // bytes per (tap, 16-channel step)
+    const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;                        // (ablation 16: weights from one address)
     const char* wbase = (const char*)p.wp + (a.z_is_phase ? (size_t)z * a.phase_wp_bytes : 0);
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wbase, (unsigned)ks * tap_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wbase, (a.ablate & 16) ? 65536u : (unsigned)ks * tap_bytes);
     const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
     const char* a_lane = lds + (wt * MT * 32 + lo) * SB + hi * 16;
     const int dil_bytes = p.dil * SB;
@@ -543,8 +543,11 @@ inline Tile pick_tile(int C_in, int C_out) {
     Tile t;
     if (C_out <= 32) {
         t.WT = 4; t.WC = 1; t.NT = 1;
-        t.MT = (v32 & 1) ? 2 : 4;
-        t.MINB = 2 + (v32 >> 1);          // v32: bit0 -> MT=2, bits1.. -> min blocks 2/3/4
+        // default: 384 rows at <= 128 VGPRs -> four blocks per CU (HBM-bound layers want requests in flight);
+        // diagnostics: v32 = 8 -> 512 rows / 3 blocks, else bit0 -> MT=2, bits1.. -> min blocks 2/3/4
+        if (v32 == 0)      { t.MT = 3; t.MINB = 4; }
+        else if (v32 == 8) { t.MT = 4; t.MINB = 2; }
+        else               { t.MT = (v32 & 1) ? 2 : 4; t.MINB = 2 + (v32 >> 1); }
     } else if (C_out <= 64) {
         t.WT = 4; t.WC = 1; t.NT = 2;
         t.MT = (v64 & 1) ? 1 : 2;
@@ -609,6 +612,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     if (t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.CIC == CIC_ && t.MINB == MINB_) \
         IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<WT_, WC_, MT_, NT_, CIC_, MINB_>)
     IRIS_B16_CASE(4, 1, 4, 1, 32, 2); IRIS_B16_CASE(4, 1, 4, 1, 32, 3); IRIS_B16_CASE(4, 1, 4, 1, 32, 4);
+    IRIS_B16_CASE(4, 1, 3, 1, 32, 4); IRIS_B16_CASE(4, 1, 3, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 1, 32, 2); IRIS_B16_CASE(4, 1, 2, 1, 32, 3); IRIS_B16_CASE(4, 1, 2, 1, 32, 4);
     IRIS_B16_CASE(4, 1, 4, 1, 64, 2); IRIS_B16_CASE(4, 1, 4, 1, 64, 3); IRIS_B16_CASE(4, 1, 4, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 1, 64, 2); IRIS_B16_CASE(4, 1, 2, 1, 64, 3); IRIS_B16_CASE(4, 1, 2, 1, 64, 4);
