@@ -22,11 +22,12 @@ class MelToWavePipeline:
     ``[B, n_mels, W] -> [B, hop*W]``)."""
 
     def __init__(self, postnet: Optional[Callable], vocode: Callable, device: Optional[torch.device] = None,
-                 hop_length: int = 256, chunk_frames: int = 256, halo_frames: int = RECEPTIVE_FIELD_FRAMES):
+                 hop_length: int = 256, chunk_frames: int = 256, halo_frames: int = RECEPTIVE_FIELD_FRAMES,
+                 group_chunks: int = 1):
         self.postnet = postnet
         self.device = device
         self.streamer = StreamingVocoder(vocode, hop_length=hop_length, chunk_frames=chunk_frames,
-                                         halo_frames=halo_frames)
+                                         halo_frames=halo_frames, group_chunks=group_chunks)
 
     def refine(self, mel) -> torch.Tensor:
         """Host or device mel ``[B, n_mels, T]`` -> refined device mel (one PostNet pass over the whole utterance:

@@ -51,23 +51,54 @@ class StreamingVocoder:
     """
 
     def __init__(self, forward: Callable, hop_length: int = 256, chunk_frames: int = 256,
-                 halo_frames: int = RECEPTIVE_FIELD_FRAMES):
+                 halo_frames: int = RECEPTIVE_FIELD_FRAMES, group_chunks: int = 1):
         if halo_frames < RECEPTIVE_FIELD_FRAMES:
             raise ValueError(
                 f"halo_frames={halo_frames} is smaller than the generator's receptive field "
                 f"({RECEPTIVE_FIELD_FRAMES} frames): chunk seams would differ from the one-shot output")
+        if group_chunks < 1:
+            raise ValueError("group_chunks >= 1 is required")
         self.forward = forward
         self.hop_length = hop_length
         self.chunk_frames = chunk_frames
         self.halo_frames = halo_frames
+        self.group_chunks = group_chunks
 
     def stream(self, mel) -> Iterator:
-        """Yields the waveform of each chunk, ``[B, hop*(stop-start)]``, in order."""
+        """Yields the waveform of each chunk, ``[B, hop*(stop-start)]``, in order.
+
+        With ``group_chunks = G > 1`` the first chunk is still vocoded alone (time to first audio is unchanged);
+        after it, up to G chunks whose windows have the same length are stacked along the batch axis and vocoded
+        in one forward -- batch items are independent, so the samples are the same, but a short window no longer
+        leaves most of the GPU idle (fp32, one MI355X: a 282-frame window takes 2.5 ms, four of them 5.5 ms)."""
         if mel.ndim != 3:
             raise ValueError(f"expected mel [B, n_mels, T], got shape {tuple(mel.shape)}")
-        for c in plan_chunks(mel.shape[2], self.chunk_frames, self.halo_frames):
-            wav = self.forward(mel[:, :, c.win_start:c.win_stop])
-            yield wav[:, c.emit_slice(self.hop_length)]
+        chunks = plan_chunks(mel.shape[2], self.chunk_frames, self.halo_frames)
+        batch = mel.shape[0]
+        i = 0
+        while i < len(chunks):
+            group = [chunks[i]]
+            if self.group_chunks > 1 and i > 0:
+                width = chunks[i].win_stop - chunks[i].win_start
+                while (len(group) < self.group_chunks and i + len(group) < len(chunks)
+                       and chunks[i + len(group)].win_stop - chunks[i + len(group)].win_start == width):
+                    group.append(chunks[i + len(group)])
+            if len(group) == 1:
+                c = group[0]
+                wav = self.forward(mel[:, :, c.win_start:c.win_stop])
+                yield wav[:, c.emit_slice(self.hop_length)]
+            else:
+                windows = [mel[:, :, c.win_start:c.win_stop] for c in group]
+                if hasattr(mel, "detach"):
+                    import torch
+                    stacked = torch.cat(windows, dim=0)
+                else:
+                    import numpy as np
+                    stacked = np.concatenate(windows, axis=0)
+                wav = self.forward(stacked)
+                for g, c in enumerate(group):
+                    yield wav[g * batch:(g + 1) * batch, c.emit_slice(self.hop_length)]
+            i += len(group)
 
     def infer(self, mel):
         """Concatenation of ``stream(mel)``; equals the one-shot forward of the whole mel."""

@@ -60,3 +60,40 @@ def test_streaming_engine_equals_one_shot_gpu():
     # same fmaf chains per output element whatever the tile origin: seams are exact to rounding
     assert (chunked - full).abs().max().item() <= 1e-6
     eng.close()
+
+
+def test_grouped_chunks_equal_ungrouped():
+    """group_chunks stacks same-width windows along the batch axis: same samples, same order, first chunk alone."""
+    calls = []
+
+    def fwd(m):                                    # +-13-frame dependence like the generator, hop 4
+        calls.append(tuple(m.shape))
+        k = np.ones(27) / 27.0
+        y = np.stack([np.convolve(m[b].sum(0), k, mode="same") for b in range(m.shape[0])])
+        return np.repeat(y, 4, axis=1)
+
+    mel = np.random.default_rng(0).standard_normal((2, 5, 1500)).astype(np.float32)
+    plain = list(StreamingVocoder(fwd, hop_length=4, chunk_frames=256).stream(mel))
+    calls.clear()
+    grouped = list(StreamingVocoder(fwd, hop_length=4, chunk_frames=256, group_chunks=3).stream(mel))
+    assert len(plain) == len(grouped) == 6
+    for a, b in zip(plain, grouped):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    # chunk 0 alone (269 frames), then chunks 1-3 stacked (6 items of 282 frames), chunk 4 alone (282), last (233)
+    assert calls == [(2, 5, 269), (6, 5, 282), (2, 5, 282), (2, 5, 233)]
+    with pytest.raises(ValueError):
+        StreamingVocoder(fwd, group_chunks=0)
+
+
+@pytest.mark.gpu
+def test_grouped_streaming_on_gpu_is_exact():
+    import torch
+    from iris._engine import GeneratorEngine
+    cfg = GeneratorConfig()
+    dev = torch.device("cuda", 0)
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0), dev)
+    mel = torch.from_numpy(seeded_mel(9, 1, 1400, log_mel=True)).to(dev)
+    one_shot = eng.forward(mel).clone()
+    grouped = StreamingVocoder(eng.forward, group_chunks=4).infer(mel)
+    assert torch.equal(grouped, one_shot)
+    eng.close()
