@@ -20,7 +20,8 @@
  *     message is available from iris_hifigan_last_error(); no exception crosses the ABI;
  *   - a handle may be used by one thread at a time.
  *
- * Activations inside the library are channels-last [B, L, C] fp32; the mel comes in as the
+ * Activations inside the library are channels-last [B, L, C], fp32 (bf16 with dtype
+ * IRIS_HIFIGAN_BF16); the mel comes in as the
  * reference hands it over, channels-first [B, n_mels, T] (hifigan_pretrained.py:228), and the
  * waveform goes out as [B, prod(upsample_rates) * T] (hifigan_pretrained.py:235-236).
  */
