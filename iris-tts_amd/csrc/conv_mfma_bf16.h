@@ -74,8 +74,9 @@ struct Launch {
     int n_co_blk;         // blocks along C_out
     int Qp;               // padded number of 16-channel steps in the packed weights
     int n_ct;             // 32-wide C_out tiles in the packed weights
-    int n_items;          // time tiles x nz
-    int xcd_group;        // C_out blocks of one window share an XCD (see the kernel)
+    int n_items;          // window items: time tiles (x nz when z is a problem index)
+    int n_share;          // consecutive sub-blocks that stage the same window: C_out blocks (x phases for a ConvTranspose)
+    int xcd_group;        // the sub-blocks of a window item share an XCD (see the kernel)
     int ablate;           // diagnostics only (env IRIS_B16_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores,
                           // 8 no residual loads, 16 every weight fragment from one (L1-resident) address.  Results are wrong.
 };
@@ -263,23 +264,24 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     const int lo = lane & 31, hi = lane >> 5;
 
     // z = MRF branch (heaviest first) or ConvTranspose phase; compile-time indices keep the kernarg in SGPRs
-    // blockIdx.x -> (row-work item r = tile_t * nz + z, C_out block).  With several C_out blocks the blocks that
-    // share an input window are given the same XCD (blockIdx.x % 8) and neighbouring slots, so the window is
-    // fetched from HBM once and re-read from that XCD's L2.
-    int r_item, tile_co;
+    // blockIdx.x -> (window item, sub-block).  Blocks that stage the SAME input window -- the C_out blocks of a
+    // tile and, for a ConvTranspose, its u output phases -- are `n_share` consecutive sub-blocks of one window item.
+    // With xcd_group they are given the same XCD (blockIdx.x % 8) and neighbouring slots, so the window is fetched
+    // from HBM once and re-read from that XCD's L2 (measured without it: the phase blocks of an upsample launch
+    // fetched the input u times, 1.5 GB instead of 0.2 GB per launch at configs[2]).
+    int w_item, sub;
     if (a.xcd_group) {
         const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-        tile_co = s % a.n_co_blk;
-        r_item = (s / a.n_co_blk) * 8 + xcd;
-        if (r_item >= a.n_items) return;
-    } else if (a.n_co_blk > 1) {
-        tile_co = blockIdx.x % a.n_co_blk;
-        r_item = blockIdx.x / a.n_co_blk;
+        sub = s % a.n_share;
+        w_item = (s / a.n_share) * 8 + xcd;
+        if (w_item >= a.n_items) return;
     } else {
-        tile_co = 0;
-        r_item = blockIdx.x;
+        sub = blockIdx.x % a.n_share;
+        w_item = blockIdx.x / a.n_share;
     }
-    const int zr = r_item % a.nz;
+    int tile_co, tile_t, zr;
+    if (a.z_is_phase) { zr = sub / a.n_co_blk; tile_co = sub - zr * a.n_co_blk; tile_t = w_item; }
+    else              { tile_co = sub; zr = w_item % a.nz; tile_t = w_item / a.nz; }
     const int z = a.z_is_phase ? zr : a.nz - 1 - zr;
     const int pz = a.z_is_phase ? 0 : z;
     Problem p = a.p[0];
@@ -288,7 +290,6 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     if (pz == 3) p = a.p[3];
     const int out_off = a.out_off + (a.z_is_phase ? z : 0);
 
-    const int tile_t = r_item / a.nz;
     const int b = blockIdx.y;
     const int i0 = tile_t * T_BLK;
     const int ks = p.ks;
@@ -592,9 +593,11 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
-    a.n_items = n_t * nz;
-    a.xcd_group = a.n_co_blk > 1 && a.n_items >= 64;      // (a few items would leave XCDs without work)
-    const int gx = a.xcd_group ? ((a.n_items + 7) / 8) * 8 * a.n_co_blk : a.n_items * a.n_co_blk;
+    a.n_items = a.z_is_phase ? n_t : n_t * nz;
+    a.n_share = a.z_is_phase ? a.n_co_blk * nz : a.n_co_blk;
+    static const int xcd_env = env_int("IRIS_B16_XCDGROUP", 1);
+    a.xcd_group = xcd_env && a.n_share > 1 && a.n_items >= 64;      // (a few items would leave XCDs without work)
+    const int gx = a.xcd_group ? ((a.n_items + 7) / 8) * 8 * a.n_share : a.n_items * a.n_share;
     dim3 grid((unsigned)gx, (unsigned)a.B, 1u), block(256);
 #define IRIS_B16_LAUNCH(...)                                                                      \
     do {                                                                                          \
