@@ -550,15 +550,16 @@ inline Tile pick_tile(int C_in, int C_out) {
         else if (v32 == 8) { t.MT = 4; t.MINB = 2; }
         else               { t.MT = (v32 & 1) ? 2 : 4; t.MINB = 2 + (v32 >> 1); }
     } else if (C_out <= 64) {
-        t.WT = 4; t.WC = 1; t.NT = 2;
-        t.MT = (v64 & 1) ? 1 : 2;
-        t.MINB = 2 + (v64 >> 1);
+        // default: 192 rows x 64 channels as 2 x 2 waves of 96 x 32 at <= 128 VGPRs -> four blocks per CU (2-3 %
+        // ahead of 256 x 64 at three blocks); diagnostics: v64 = 8 -> 256 x 64, else bit0 -> MT=1, bits1.. -> min blocks
+        if (v64 == 0)      { t.WT = 2; t.WC = 2; t.MT = 3; t.NT = 1; t.MINB = 4; }
+        else               { t.WT = 4; t.WC = 1; t.NT = 2; t.MT = (v64 & 1) ? 1 : 2; t.MINB = v64 == 8 ? 2 : 2 + (v64 >> 1); }
     } else {
         t.WT = 2; t.WC = 2; t.NT = 2;
         t.MT = 2;
         t.MINB = 2;
     }
-    t.CIC = (C_in <= 32 && t.NT == 1) ? 32 : 64;
+    t.CIC = (C_in <= 32 && t.NT == 1 && t.WC == 1) ? 32 : 64;
     // wide layers: 128-channel chunks halve the staging round trips of a block (window 48 KB, three blocks per CU)
     if (C_out > 64 && !(v128 & 2) && C_in % 128 == 0) t.CIC = 128;
     t.T_BLK = t.WT * t.MT * 32;
@@ -621,7 +622,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     IRIS_B16_CASE(4, 1, 2, 1, 64, 2); IRIS_B16_CASE(4, 1, 2, 1, 64, 3); IRIS_B16_CASE(4, 1, 2, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 2, 64, 2); IRIS_B16_CASE(4, 1, 2, 2, 64, 3); IRIS_B16_CASE(4, 1, 2, 2, 64, 4);
     IRIS_B16_CASE(4, 1, 1, 2, 64, 2); IRIS_B16_CASE(4, 1, 1, 2, 64, 3); IRIS_B16_CASE(4, 1, 1, 2, 64, 4);
-    IRIS_B16_CASE(2, 2, 2, 2, 64, 2); IRIS_B16_CASE(2, 2, 2, 2, 128, 2);
+    IRIS_B16_CASE(2, 2, 2, 2, 64, 2); IRIS_B16_CASE(2, 2, 2, 2, 128, 2); IRIS_B16_CASE(2, 2, 3, 1, 64, 4);
 #undef IRIS_B16_CASE
 #undef IRIS_B16_LAUNCH
     return hipErrorInvalidValue;
