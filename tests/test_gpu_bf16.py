@@ -68,6 +68,7 @@ CONV_CASES = [
     (1, 130, 128, 128, 7, 5, 1, True), (2, 259, 128, 128, 3, 1, 1, False),
     (1, 70, 256, 256, 11, 3, 1, True), (1, 264, 256, 256, 3, 1, 1, False),
     (1, 5, 32, 32, 11, 5, 1, True), (1, 1, 64, 64, 3, 1, 1, False), (3, 41, 24, 40, 5, 2, 1, False),
+    (1, 9000, 256, 256, 3, 1, 1, True),    # 71 window items x 2 C_out blocks: the XCD-grouped block mapping, ragged
 ]
 
 
@@ -99,7 +100,8 @@ def test_bf16_conv1d_matches_oracle(B, L, Ci, Co, k, d, act, use_res):
 
 
 @pytest.mark.parametrize("B,L,Ci,Co,k,u", [(1, 40, 512, 256, 16, 8), (2, 130, 256, 128, 16, 8), (1, 300, 128, 64, 4, 2),
-                                            (2, 517, 64, 32, 4, 2), (1, 1, 64, 32, 4, 2), (1, 9, 32, 16, 7, 3)])
+                                            (2, 517, 64, 32, 4, 2), (1, 1, 64, 32, 4, 2), (1, 9, 32, 16, 7, 3),
+                                            (1, 25000, 64, 32, 4, 2)])   # 66 window items x 2 phases: XCD-grouped
 def test_bf16_conv_transpose1d_matches_oracle(B, L, Ci, Co, k, u):
     from iris import _native
     lib = _native.load()
