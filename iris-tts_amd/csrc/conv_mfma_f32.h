@@ -80,6 +80,8 @@ struct ConvLaunch {
     int n_co_blk;        // blocks along C_out
     int Gp;              // padded number of 8-channel groups in the packed weights
     int n_ct;            // number of 32-wide C_out tiles in the packed weights
+    unsigned* dyn_counter;  // MRF kernel: when set (zero at launch), blocks take their 2nd, 3rd, ... tile from this
+                            // counter instead of a fixed stride (large batches: evens out slow and fast CUs)
 };
 
 __device__ __forceinline__ float lrelu1(float v, float slope) { return v > 0.f ? v : v * slope; }

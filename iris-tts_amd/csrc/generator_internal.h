@@ -51,6 +51,7 @@ struct iris_hifigan_handle {
     std::vector<iris::Stage> stages;
     float* blob = nullptr;   // device: packed fp32 weights + biases
     size_t blob_floats = 0;
+    unsigned* tile_counters = nullptr;  // device: one next-tile counter per MRF launch of a forward (zeroed per forward)
     uint16_t* blob16 = nullptr;  // device: packed bf16 weights (biases stay fp32 in `blob`)
     size_t blob16_halfs = 0;
     int hop = 1;

@@ -222,6 +222,7 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "weight upload failed: %s", hipGetErrorString(e));
     }
+    if (hipMalloc(&h->tile_counters, 256 * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
     const int rc16 = bf16_build_blob(h, weights_host);
     if (rc16 != IRIS_HIFIGAN_OK) {
         (void)hipFree(h->blob);
@@ -237,6 +238,7 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     if (h->blob) (void)hipFree(h->blob);
     if (h->blob16) (void)hipFree(h->blob16);
+    if (h->tile_counters) (void)hipFree(h->tile_counters);
     delete h;
     return IRIS_HIFIGAN_OK;
 }
@@ -303,6 +305,11 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     const int nk = h->cfg.num_kernels;
     Prof prof{h, stream, h->profiling ? h->n_rec : 0};
     const double fB = (double)B;
+    // large batches: the MRF kernel's blocks draw tiles from per-launch counters (mrf_conv_mfma_f32.h); one
+    // memset per forward zeroes them.  Below ~2000 frames no launch has enough tiles per block to use them.
+    const bool dyn_tiles = h->tile_counters && (long long)B * T >= 2000 &&
+                           (int)h->stages.size() * 2 * h->cfg.num_dilations[0] <= 256;
+    if (dyn_tiles) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, 256 * sizeof(unsigned), stream));
 
     // ---- conv_pre (hifigan_pretrained.py:124) ----
     {
@@ -373,6 +380,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 }
                 a.B = B; a.L_in = L_out; a.L_out = L_out; a.C_in = st.C; a.C_out = st.C;
                 a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
+                a.dyn_counter = dyn_tiles ? h->tile_counters + ((int)i * 2 * nd + 2 * m + half) : nullptr;
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops,
                                4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
                 static const int stop_after = [] { const char* e = getenv("IRIS_HIFIGAN_STOP_AFTER_MRF"); return e ? atoi(e) : -1; }();

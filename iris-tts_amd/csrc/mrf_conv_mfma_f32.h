@@ -390,11 +390,16 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         if (tile >= n_tiles) return;
         Tile t = make_tile(tile);
         prologue(I2{}, t);
+        // dynamic mode: the next tile index comes from a global counter (first tile = blockIdx.x).  Thread 0 fetches
+        // it at the start of a tile and leaves it in an LDS word behind the window; everybody reads it after the
+        // barriers that end the first branch -- long before the last branch needs it for its prefetch.
+        unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (T_BLK + kMrfSpanMax) * S);
         for (;;) {
-            const int tile_next = tile + (int)gridDim.x;
+            if (a.dyn_counter && tid == 0) *next_slot = gridDim.x + atomicAdd(a.dyn_counter, 1u);
+            run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
+            const int tile_next = a.dyn_counter ? (int)*next_slot : tile + (int)gridDim.x;
             const bool more = tile_next < n_tiles;
             const Tile tn = make_tile(more ? tile_next : tile);
-            run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
             run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
             run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
             if (!more) break;
@@ -507,7 +512,10 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     a.ablate = ablate_env;
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr);
     const int T_BLK = t.WT * pl.MT * 32;
-    const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float);
+    const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;   // + next-tile word
+    // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
+    static const int dyn_env = [] { const char* e = getenv("IRIS_HIFIGAN_DYNTILES"); return e ? atoi(e) : 1; }();
+    if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
     const long long n_tiles = pl.n_tiles, g = pl.grid;
     if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
