@@ -330,7 +330,9 @@ def test_hipgraph_replay_matches_eager(dev):
     from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
     cfg = GeneratorConfig()
     eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0), dev)
-    for (B, T) in ((1, 64), (2, 33), (1, 300), (1, 64)):          # (1,300) grows the workspace; (1,64) is re-captured
+    # (1,300) grows the workspace; (1,64) is re-captured; (3,700) is large enough for the per-forward memset of the
+    # MRF kernel's tile counters, which must be part of the captured graph
+    for (B, T) in ((1, 64), (2, 33), (1, 300), (1, 64), (3, 700)):
         for seed in (1, 2):
             mel = torch.from_numpy(seeded_mel(seed, B, T, log_mel=True)).to(dev)
             eager = eng.forward(mel).clone()
