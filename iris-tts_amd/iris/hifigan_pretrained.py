@@ -52,6 +52,12 @@ class _WeightNormedConv(nn.Module):
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape(-1, 1, 1).clone(), requires_grad=False)
         self.weight_v = nn.Parameter(v, requires_grad=False)
 
+    @property
+    def weight(self) -> torch.Tensor:
+        """The folded weight ``v * g / ||v||``, like ``module.weight`` of a ``torch.nn.utils.weight_norm`` module
+        (what the reference's layers expose, hifigan_pretrained.py:49-57)."""
+        return torch._weight_norm(self.weight_v, self.weight_g, 0)
+
 
 class ResBlock(nn.Module):
     """Parameters of one MRF branch: ``convs1[m]`` (dilated) and ``convs2[m]`` (dilation 1)

@@ -378,3 +378,27 @@ def test_bench_collective_path_runs_on_rccl(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_integration_md_ctypes_stub_runs(dev):
+    """The ctypes stub printed in INTEGRATION.md section 2 (what a reference maintainer would paste) is executed as
+    written -- only the library name is made absolute -- against a model with the reference's attribute layout."""
+    import re
+    from pathlib import Path
+    from iris import _native
+    from iris.hifigan_pretrained import HiFiGANModel
+    from iris._weights import seeded_mel
+    text = (Path(__file__).resolve().parents[1] / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n# src/iris/_hifigan_mi355x\.py.*?\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libiris_hifigan.so")', f'ctypes.CDLL("{_native.library_path()}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    torch.manual_seed(0)
+    model = HiFiGANModel().to(dev)
+    gen = ns["MI355XGenerator"](model)
+    mel = torch.from_numpy(seeded_mel(3, 2, 40)).to(dev)
+    got = gen(mel)
+    want = model(mel)
+    assert got.shape == want.shape == (2, 1, 40 * 256)
+    # (the stub folds weight-norm with torch, the module with numpy: last-bit differences in the weights)
+    assert (got - want).abs().max().item() <= 1e-5
