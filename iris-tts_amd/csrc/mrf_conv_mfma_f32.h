@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             if (a.dyn_counter && tid == 0) *next_slot = gridDim.x + atomicAdd(a.dyn_counter, 1u);
             run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
             const int tile_next = a.dyn_counter ? (int)*next_slot : tile + (int)gridDim.x;
-            const bool more = tile_next < n_tiles;
+            const bool more = (unsigned)tile_next < (unsigned)n_tiles;
             const Tile tn = make_tile(more ? tile_next : tile);
             run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
             run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
