@@ -407,12 +407,15 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             t = tn;
         }
     } else {
-        // latency mode for small problems (fewer tiles than CUs): one branch per block, so a stage
-        // step is spread over 3x the blocks.  gridDim.x is a multiple of 3; block b serves branch
-        // 2 - b%3 (heaviest first in dispatch order) for tiles b/3, b/3 + gridDim.x/3, ...
-        const int zb = 2 - (int)(blockIdx.x % 3u);
-        const int step = (int)(gridDim.x / 3u);
-        int tile = (int)(blockIdx.x / 3u);
+        // One branch per block: a stage step is spread over 3x the jobs, which fills the chip when there are fewer
+        // tiles than block slots and softens the round quantisation of the tile-serial mode in between.  Each
+        // branch has its own range of blocks, sized by the host so that the three finish together (mrf_plan):
+        // [0, zb1) branch 2 (k = 11, first in dispatch order), [zb1, zb2) branch 1, [zb2, gridDim.x) branch 0;
+        // a block walks the tiles  first, first + (blocks of its branch), ...
+        const int bx = (int)blockIdx.x;
+        const int zb = bx < a.zb1 ? 2 : (bx < a.zb2 ? 1 : 0);
+        const int step = zb == 2 ? a.zb1 : (zb == 1 ? a.zb2 - a.zb1 : (int)gridDim.x - a.zb2);
+        int tile = zb == 2 ? bx : (zb == 1 ? bx - a.zb1 : bx - a.zb2);
         if (tile >= n_tiles) return;
         Tile t = make_tile(tile);
         auto walk = [&](auto ks_tag, auto pi_tag) {
@@ -462,7 +465,7 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
 }
 
 // How a grouped MRF step is spread over the chip.
-struct MrfPlan { int MT; bool zpar; long long n_tiles; long long grid; };
+struct MrfPlan { int MT; bool zpar; long long n_tiles; long long grid; int zb1, zb2; };
 
 inline int mrf_cu_count() {
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
@@ -470,33 +473,67 @@ inline int mrf_cu_count() {
     return n_cu;
 }
 
-// Persistent grid of at most `per_cu` blocks per CU, evened out so that every block walks the same
-// number of tiles (+-1): 1000 tiles on 256 CUs x 2 -> 2 rounds -> 500 blocks of 2 tiles.
-// Small problems: with fewer than 2 tiles per CU the tile height is halved (MT = 1); if that still
-// leaves CUs without a block, every branch gets its own blocks (zpar, 3x the blocks, unequal cost).
+// Tile-serial mode: a persistent grid of at most `per_cu` blocks per CU; every block runs the three branches of its
+// tiles (equal cost) and the grid is evened out so that every block walks the same number of tiles (+-1): 1000
+// tiles on 256 CUs x 2 -> 2 rounds -> 500 blocks of 2 tiles.  Time ~ rounds x 21 tap-units per 32 rows of tile.
+// One-branch-per-block mode (zpar, half-height tiles): jobs are (tile, branch) of 11 / 7 / 3 units; branch c gets
+// nb_c blocks which each walk ceil(tiles / nb_c) tiles, so the step takes max_c ceil(tiles / nb_c) x cost_c.  The
+// block counts are the ones that minimise that under nb_11 + nb_7 + nb_3 <= slots.  The mode with the smaller
+// estimate is taken (half-height tiles and zpar carry a few per cent overhead): zpar wins when there are few
+// tiles or their number falls between multiples of the slot count (T = 100 ... 400 frames at batch 1).
 inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar) {
     static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
-    static const int plan_env = [] { const char* e = getenv("IRIS_HIFIGAN_MRFPLAN"); return e ? atoi(e) : -1; }();  // diagnostics: 0 MT2, 1 MT1, 2 MT1+zpar
+    static const int plan_env = [] { const char* e = getenv("IRIS_HIFIGAN_MRFPLAN"); return e ? atoi(e) : -1; }();  // diagnostics: 0 MT2, 1 MT1, 2 MT1+zpar, 3 the round-1 rule
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     const int n_cu = mrf_cu_count();
     const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
+    const long long slots = (long long)n_cu * per_cu;
     const int n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     auto tiles = [&](int MT) { return (long long)((a.L_out + t.WT * MT * 32 - 1) / (t.WT * MT * 32)) * n_co_blk * a.B; };
+    // best split of the slots among the branches for n half-height tiles: smallest M with sum_c ceil(n / floor(M / cost_c)) <= slots
+    static const int cost[3] = {3, 7, 11};            // branch 0, 1, 2
+    long long nb[3] = {1, 1, 1};
+    double zpar_units = 1e30;
+    const long long n1 = tiles(1);
+    if (allow_zpar && n1 > 0) {
+        double bestM = 1e30;
+        for (int c = 0; c < 3; ++c)
+            for (long long r = 1; r <= 4096; r = r < 64 ? r + 1 : r * 2) {
+                const long long M = r * cost[c];
+                if ((double)M >= bestM) break;
+                long long sum = 0, cand[3];
+                bool ok = true;
+                for (int d = 0; d < 3; ++d) {
+                    const long long rd = M / cost[d];
+                    if (rd < 1) { ok = false; break; }
+                    cand[d] = (n1 + rd - 1) / rd;
+                    sum += cand[d];
+                }
+                if (ok && sum <= slots) { bestM = (double)M; nb[0] = cand[0]; nb[1] = cand[1]; nb[2] = cand[2]; }
+            }
+        zpar_units = bestM * 1.03 * 1.06;
+    }
     MrfPlan pl;
-    pl.MT = 2; pl.zpar = false;
-    if (plan_env >= 0) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar; }
-    else if (4 * tiles(2) < 3LL * n_cu * per_cu) {          // fewer than ~1.5 tiles per CU
-        pl.MT = 1;
-        pl.zpar = allow_zpar && tiles(1) < n_cu;
+    pl.MT = 2; pl.zpar = false; pl.zb1 = pl.zb2 = 0;
+    if (plan_env >= 0 && plan_env <= 2) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar && zpar_units < 1e29; }
+    else if (plan_env == 3) {
+        if (4 * tiles(2) < 3 * slots) { pl.MT = 1; pl.zpar = allow_zpar && tiles(1) < n_cu && zpar_units < 1e29; }
+    } else {
+        auto serial = [&](int MT) { return (double)((tiles(MT) + slots - 1) / slots) * 21.0 * MT * (MT == 1 ? 1.03 : 1.0); };
+        double best = serial(2);
+        if (serial(1) < 0.999 * best) { best = serial(1); pl.MT = 1; }
+        if (zpar_units < 0.999 * best) { best = zpar_units; pl.MT = 1; pl.zpar = true; }
     }
     pl.n_tiles = tiles(pl.MT);
-    long long cap = (long long)n_cu * per_cu;
-    if (pl.zpar) cap = cap / 3 > 0 ? cap / 3 : 1;
-    long long g = pl.n_tiles < cap ? pl.n_tiles : cap;
+    if (pl.zpar) {
+        pl.zb1 = (int)nb[2]; pl.zb2 = (int)(nb[2] + nb[1]); pl.grid = nb[2] + nb[1] + nb[0];
+        return pl;
+    }
+    long long g = pl.n_tiles < slots ? pl.n_tiles : slots;
     if (g < 1) g = 1;
     const long long rounds = (pl.n_tiles + g - 1) / g;
     g = (pl.n_tiles + rounds - 1) / rounds;
-    pl.grid = pl.zpar ? 3 * g : g;
+    pl.grid = g;
     return pl;
 }
 
@@ -516,6 +553,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
     static const int dyn_env = [] { const char* e = getenv("IRIS_HIFIGAN_DYNTILES"); return e ? atoi(e) : 1; }();
     if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
+    a.zb1 = pl.zb1; a.zb2 = pl.zb2;
     const long long n_tiles = pl.n_tiles, g = pl.grid;
     if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
