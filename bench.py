@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="mels per GPU (default: configs[1], batch 1)")
     ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
                     help="f32 = the parity path and the headline (default); bf16 = bf16 storage + bf16 MFMA "
                          "(BASELINE.json configs[2] with --batch 32 --frames 500)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,10 +201,13 @@ def main():
         dom = by_kind["mrf_resblock_conv"]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        if args.dtype == "f32":
-            roofline = {"kernel": "mrf_conv_mfma_f32_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
-                        "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": committed_traffic(B, T),
+        if args.dtype in ("f32", "f32s"):
+            # f32s: three bf16 MFMAs per fp32 product -> the matrix roof for fp32-equivalent FLOP is a third of the bf16 peak
+            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+            roofline = {"kernel": ("mrf_conv_mfma_f32_kernel" if args.dtype == "f32" else "conv_mfma_f32s_kernel (split-bf16 products)")
+                                  + " (MRF ResBlock Conv1d steps, 24 launches/forward)",
+                        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": committed_traffic(B, T) if args.dtype == "f32" else None,
                         "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
                         "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
                         "bytes_per_launch": dom["bytes"] / dom["n"],
@@ -233,7 +236,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"HiFiGAN-V1 generator, batch {B} per GPU x 80-mel x {T} frames -> {T * eng.hop_length} samples "
-                               f"each, " + ("fp32" if args.dtype == "f32" else "bf16 storage / fp32 accumulate")
+                               f"each, " + {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
+                                            "f32s": "fp32 storage, split-bf16 products in the ResBlock convs"}[args.dtype]
                                + (" (BASELINE.json configs[1])" if (B, T, args.dtype) == (1, 1000, "f32") else "")
                                + (" (BASELINE.json configs[2])" if (B, T, args.dtype) == (32, 500, "bf16") else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "frames": T, "hop_length": eng.hop_length,

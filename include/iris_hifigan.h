@@ -50,9 +50,13 @@ typedef enum iris_hifigan_status {
 
 typedef enum iris_hifigan_dtype {
     IRIS_HIFIGAN_F32 = 0, /* fp32 storage, fp32 MFMA (exact fmaf chains): the parity path (<= 1e-4 vs reference) */
-    IRIS_HIFIGAN_BF16 = 1 /* bf16 storage of activations and weights, fp32 accumulation (bf16 MFMA); mel in and
+    IRIS_HIFIGAN_BF16 = 1, /* bf16 storage of activations and weights, fp32 accumulation (bf16 MFMA); mel in and
                              waveform out stay fp32.  BASELINE.json configs[2].  The reference has no bf16 path:
                              its error against the fp32 generator (~1e-2 max-abs) is documented, not pinned. */
+    IRIS_HIFIGAN_F32_SPLIT = 2 /* fp32 storage everywhere, fp32 accumulation; the ResBlock convolutions form each product
+                             from two bf16 terms per operand (hi*hi + hi*mid + mid*hi on the bf16 MFMA).  Within
+                             north_star's 1e-4 of the fp32 generator (measured ~2e-5) but not the exact fp32 arithmetic
+                             of IRIS_HIFIGAN_F32: opt-in, never the headline.  Same workspace as IRIS_HIFIGAN_F32. */
 } iris_hifigan_dtype;
 
 /* Generator hyper-parameters: the constructor arguments of HiFiGANModel
@@ -156,6 +160,11 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
 int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
                                               void* y_dev, int32_t B, int32_t L, int32_t C_in, int32_t C_out,
                                               int32_t k, int32_t u, int32_t in_act, float slope, void* stream);
+/* the ResBlock Conv1d (C -> C, LeakyReLU on the input, optional residual) with fp32 tensors and split-bf16 products
+ * (dtype IRIS_HIFIGAN_F32_SPLIT; C % 32 == 0): hifigan_pretrained.py:50-57,64-71. */
+int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,
+                                    float* y_dev, int32_t B, int32_t L, int32_t C, int32_t k, int32_t dilation, float slope,
+                                    void* stream);
 
 /* ---- PostNet, the layer in front of the vocoder --------------------------
  * Replaces `postnet(mel_bt_f, training=False)` (scripts/synthesize.py:148-166; model src/iris/postnet.py:48-67):

@@ -1,0 +1,349 @@
+// conv_mfma_f32s.h -- MRF ResBlock conv step with fp32 storage and split-bf16 products (dtype IRIS_HIFIGAN_F32_SPLIT).
+//
+// Same layer as mrf_conv_mfma_f32.h (reference: ResBlock.forward, src/iris/hifigan_pretrained.py:64-71): activations,
+// bias, residual and output are fp32 in HBM exactly as in the fp32 path (same workspace), accumulation is fp32.
+// Only the products differ: every fp32 operand is split into two bf16 terms, v = hi + mid + O(2^-16 |v|) with
+// hi = bf16(v), mid = bf16(v - hi), and a product x*w is formed as  hi*hi + hi*mid + mid*hi  on
+// v_mfma_f32_32x32x16_bf16 (three bf16 MFMAs = 3/16 of the fp32 MFMA time per product; the dropped terms are
+// O(2^-16) of the product).  Measured on the CPU restatement of this scheme: <= 2.5e-5 max-abs on the waveform
+// against the fp32 generator, inside north_star's 1e-4 -- but it is NOT the exact fp32 arithmetic of the parity
+// path, so it is an opt-in mode and never the headline.
+//
+// Structure = conv_mfma_bf16.h: a block owns (WT*MT*32) rows x (WC*NT*32) channels; the activated window is staged
+// into LDS as two bf16 planes (hi, mid; same bytes as an fp32 window), weights are packed on the host as two
+// planes of MFMA fragments; D = W x X^T; per-wave LDS transpose in the epilogue for coalesced 16-byte fp32 stores.
+#pragma once
+#include <vector>
+
+#include "conv_mfma_bf16.h"
+
+namespace iris {
+namespace s3 {
+
+using b16::bf16x8;
+using b16::f32x4;
+using b16::f32x16;
+using b16::u32x2;
+using b16::u32x4;
+using b16::pack_bf2;
+using b16::bf_lo;
+using b16::bf_hi;
+using b16::lrelu1;
+using b16::make_rsrc;
+using b16::buf_load4;
+using b16::kOob;
+
+constexpr int kMaxGroup = 4;
+
+struct Problem {
+    const float* x;       // fp32 [B, L, C]
+    const void* wp;       // packed bf16 fragments: hi plane, then (plane_bytes later) the mid plane
+    const float* bias;    // [C] fp32
+    const float* res;     // fp32 residual [B, L, C] or nullptr
+    float* y;             // fp32 output [B, L, C]
+    int ks, dil, pad_left, reserved;
+};
+
+struct Launch {
+    Problem p[kMaxGroup];
+    int B, L, C;          // C_in == C_out
+    float slope;
+    int nz;               // problems interleaved along blockIdx.x
+    int n_co_blk, Qp, n_ct;
+    unsigned plane_bytes[kMaxGroup];   // bytes of one weight plane of problem j (= ks * Qp * n_ct * 1024)
+};
+
+// Rows [in_row0, in_row0 + R) x channels [c0, c0 + CIC) of LeakyReLU(x) -> two bf16 planes in LDS.
+template <int CIC>
+__device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, char* lds_hi, char* lds_mid, int b,
+                                             int in_row0, int R, int c0) {
+    constexpr int SB = CIC * 2 + 16;
+    constexpr int PPR = CIC / 4;          // 16-byte fp32 pieces (4 channels) per row
+    const int tid = threadIdx.x;
+    const unsigned tensor_bytes = (unsigned)a.L * (unsigned)a.C * 4u;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (size_t)b * a.L * a.C, tensor_bytes);
+    const int total = R * PPR;
+    constexpr int U = 4;
+    for (int base = 0; base < total; base += 256 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int r = idx / PPR, pc = idx - r * PPR;
+            const int row = in_row0 + r;
+            const bool ok = idx < total && row >= 0 && row < a.L;
+            v[u] = buf_load4(xr, ok ? (unsigned)(row * a.C + c0 + 4 * pc) * 4u : kOob, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int r = idx / PPR, pc = idx - r * PPR;
+            float f[4], h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned w = v[u][e];      // (bit_cast straight from a vector element reads element 0: copy first)
+                f[e] = lrelu1(__builtin_bit_cast(float, w), a.slope);
+            }
+            u32x2 hi, mid;
+            hi[0] = pack_bf2(f[0], f[1]); hi[1] = pack_bf2(f[2], f[3]);
+            h[0] = bf_lo(hi[0]); h[1] = bf_hi(hi[0]); h[2] = bf_lo(hi[1]); h[3] = bf_hi(hi[1]);
+            mid[0] = pack_bf2(f[0] - h[0], f[1] - h[1]); mid[1] = pack_bf2(f[2] - h[2], f[3] - h[3]);
+            if (idx < total) {
+                *reinterpret_cast<u32x2*>(lds_hi + r * SB + pc * 8) = hi;
+                *reinterpret_cast<u32x2*>(lds_mid + r * SB + pc * 8) = mid;
+            }
+        }
+    }
+}
+
+template <int WT, int WC, int MT, int NT, int CIC, int MINB>
+__global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_s3[];
+    char* lds = lds_s3;
+    constexpr int SB = CIC * 2 + 16;
+    constexpr int QPC = CIC / 16;
+    constexpr int QL = QPC == 4 ? 2 : 1;
+    static_assert(QPC == 4 || QPC == 2, "CIC must be 32 or 64");
+    constexpr int T_BLK = WT * MT * 32;
+    constexpr int D = 2;                                   // weight ring depth (groups of 3*MT*NT MFMAs)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = wave / WC, wc = wave - wt * WC;
+    const int lo = lane & 31, hi = lane >> 5;
+
+    // blockIdx.x -> (time tile, branch z heaviest first, C_out block)
+    const int sub = blockIdx.x % a.n_co_blk, item = blockIdx.x / a.n_co_blk;
+    const int zr = item % a.nz, tile_t = item / a.nz;
+    const int z = a.nz - 1 - zr;
+    Problem p = a.p[0];
+    unsigned plane_bytes = a.plane_bytes[0];
+    if (z == 1) { p = a.p[1]; plane_bytes = a.plane_bytes[1]; }
+    if (z == 2) { p = a.p[2]; plane_bytes = a.plane_bytes[2]; }
+    if (z == 3) { p = a.p[3]; plane_bytes = a.plane_bytes[3]; }
+    const int b = blockIdx.y;
+    const int i0 = tile_t * T_BLK;
+    const int ks = p.ks;
+    const int span = (ks - 1) * p.dil;
+    const int R = T_BLK + span;
+    const int in_row0 = i0 - p.pad_left;
+    const int ct0 = (sub * WC + wc) * NT;
+    char* const lds_hi = lds;
+    char* const lds_mid = lds + R * SB;              // second plane right behind the first (SB is a multiple of 16)
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+
+    const unsigned q_bytes = (unsigned)a.n_ct * 1024u;
+    const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, 2u * plane_bytes);
+    const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
+    const int a_off = (wt * MT * 32 + lo) * SB + hi * 16;
+    const int dil_bytes = p.dil * SB;
+    const int NG = ks * QPC;
+
+    for (int c0 = 0; c0 < a.C; c0 += CIC) {
+        if (c0 > 0) __syncthreads();
+        stage_window<CIC>(a, p, lds_hi, lds_mid, b, in_row0, R, c0);
+        __syncthreads();
+        const unsigned q0_bytes = (unsigned)(c0 >> 4) * q_bytes;
+        auto w_soff = [&](int n) -> unsigned {      // groups past the last tap fall outside the hi plane's range -> clamp below
+            return (unsigned)(n >> QL) * tap_bytes + q0_bytes + (unsigned)(n & (QPC - 1)) * q_bytes;
+        };
+        auto load_w = [&](u32x4 (&wh)[NT], u32x4 (&wm)[NT], int n) {
+            const bool in = n < NG;                 // (the ring asks for up to D groups beyond the end)
+            const unsigned so = w_soff(in ? n : 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wh[nt] = buf_load4(wr, in ? wvoff + (unsigned)nt * 1024u : kOob, so);
+                wm[nt] = buf_load4(wr, in ? wvoff + (unsigned)nt * 1024u : kOob, so + plane_bytes);
+            }
+        };
+        auto load_a = [&](u32x4 (&ah)[MT], u32x4 (&am)[MT], int n) {
+            int tap = n >> QL;
+            tap = tap < ks ? tap : ks - 1;
+            const int off = a_off + tap * dil_bytes + (n & (QPC - 1)) * 32;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *reinterpret_cast<const u32x4*>(lds_hi + off + m * 32 * SB);
+                am[m] = *reinterpret_cast<const u32x4*>(lds_mid + off + m * 32 * SB);
+            }
+        };
+        u32x4 wh[D][NT], wm[D][NT], ah[2][MT], am[2][MT];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            load_w(wh[i], wm[i], i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_a(ah[0], am[0], 0);
+        for (int n0 = 0; n0 < NG; n0 += D) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int n = n0 + i;
+                load_a(ah[(i + 1) & 1], am[(i + 1) & 1], n + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        // smallest terms first: (w_mid, x_hi) + (w_hi, x_mid) + (w_hi, x_hi)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wm[i][nt]), __builtin_bit_cast(bf16x8, ah[i & 1][m]), acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wh[i][nt]), __builtin_bit_cast(bf16x8, am[i & 1][m]), acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, wh[i][nt]), __builtin_bit_cast(bf16x8, ah[i & 1][m]), acc[m][nt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                load_w(wh[i], wm[i], n + D);
+            }
+        }
+    }
+
+    // Epilogue: (acc + bias) -> per-wave fp32 scratch [row][channel] -> 16-byte pieces (4 channels of one row), + residual,
+    // coalesced fp32 stores.  The scratch aliases the window: every wave must be done with it first.
+    __syncthreads();
+    constexpr int RS = NT * 32 * 4 + 16;
+    constexpr int PPRO = NT * 8;                       // 16-byte fp32 pieces per row of this wave's channel span
+    constexpr int NP = 4 * NT;                         // pieces per lane and 32-row m-tile
+    char* const scr = lds + wave * (32 * RS);
+    const unsigned tensor_bytes = (unsigned)a.L * (unsigned)a.C * 4u;
+    const size_t ob = (size_t)b * a.L * a.C;
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + ob, tensor_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, p.res ? tensor_bytes : 0u);
+    unsigned pv[NP];
+    int pscr[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = j * 64 + lane;
+        const int row_l = q / PPRO, pc = q - row_l * PPRO;
+        pscr[j] = row_l * RS + pc * 16;
+        pv[j] = (unsigned)((i0 + wt * MT * 32 + row_l) * a.C + ct0 * 32 + 4 * pc) * 4u;    // rows >= L exceed num_records
+    }
+    f32x4 bias4[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (ct0 + nt) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const unsigned msoff = (unsigned)(m * 32 * a.C) * 4u;
+        u32x4 resv[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) resv[j] = buf_load4(rr, pv[j], msoff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e] + bias4[nt][g][e];
+                *reinterpret_cast<f32x4*>(scr + lo * RS + (nt * 32 + 8 * g + 4 * hi) * 4) = v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 outp[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(scr + pscr[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned rw = resv[j][e];
+                const float o = v[e] + __builtin_bit_cast(float, rw);
+                outp[j][e] = __builtin_bit_cast(unsigned, o);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)pv[j], (int)msoff, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // store data stays live until every store of the group has issued (store-data note in mrf_conv_mfma_f32.h)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) asm volatile("" :: "v"(outp[j]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+// Two planes of the bf16 fragment layout of conv_mfma_bf16.h (pack_conv1d_bf16): hi = bf16(w), mid = bf16(w - hi).
+inline size_t packed_plane_halfs(int C_in, int C_out, int ks) { return b16::packed_conv1d_halfs(C_in, C_out, ks); }
+inline void pack_conv1d_split(const float* w, int C_in, int C_out, int ks, uint16_t* out) {
+    const size_t n = (size_t)C_out * C_in * ks;
+    std::vector<float> hi(n), mid(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t h = b16::f32_to_bf16(w[i]);
+        uint32_t u = (uint32_t)h << 16;
+        float hf;
+        memcpy(&hf, &u, 4);
+        hi[i] = hf;
+        mid[i] = w[i] - hf;
+    }
+    b16::pack_conv1d_bf16(hi.data(), C_in, C_out, ks, out);
+    b16::pack_conv1d_bf16(mid.data(), C_in, C_out, ks, out + packed_plane_halfs(C_in, C_out, ks));
+}
+
+struct Tile { int WT, WC, MT, NT, CIC, MINB, T_BLK, CO_BLK; };
+inline Tile pick_tile(int C) {
+    Tile t;
+    if (C <= 32)      { t.WT = 4; t.WC = 1; t.MT = 2; t.NT = 1; t.CIC = 32; }
+    else if (C <= 64) { t.WT = 2; t.WC = 2; t.MT = 2; t.NT = 1; t.CIC = 64; }
+    else              { t.WT = 2; t.WC = 2; t.MT = 2; t.NT = 2; t.CIC = 64; }
+    t.MINB = 2;
+    t.T_BLK = t.WT * t.MT * 32;
+    t.CO_BLK = t.WC * t.NT * 32;
+    return t;
+}
+
+inline bool applicable(const Launch& a, int nz) {
+    if (nz < 1 || nz > kMaxGroup || a.C < 32 || (a.C & 31)) return false;
+    const Tile t = pick_tile(a.C);
+    if (a.C % t.CIC || a.C % t.CO_BLK) return false;
+    if ((double)a.L * a.C * 4.0 >= 2147483648.0 - 4194304.0) return false;       // 32-bit buffer offsets
+    return true;
+}
+
+inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
+    const Tile t = pick_tile(a.C);
+    a.n_co_blk = a.C / t.CO_BLK;
+    a.Qp = b16::packed_qsteps(a.C);
+    a.n_ct = b16::packed_cotiles(a.C);
+    a.nz = nz;
+    int span = 0;
+    for (int j = 0; j < nz; ++j) {
+        const int s = (a.p[j].ks - 1) * a.p[j].dil;
+        if (s > span) span = s;
+        a.plane_bytes[j] = (unsigned)(packed_plane_halfs(a.C, a.C, a.p[j].ks) * 2);
+    }
+    const int SB = t.CIC * 2 + 16;
+    const size_t window = 2 * (size_t)(t.T_BLK + span) * SB;
+    const size_t scratch = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);
+    const size_t lds_bytes = window > scratch ? window : scratch;
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const int n_t = (a.L + t.T_BLK - 1) / t.T_BLK;
+    dim3 grid((unsigned)(n_t * nz * a.n_co_blk), (unsigned)a.B, 1u), block(256);
+#define IRIS_S3_LAUNCH(...)                                                                       \
+    do {                                                                                          \
+        auto kfn = __VA_ARGS__;                                                                   \
+        if (lds_bytes > 64 * 1024) {                                                              \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               (int)lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+        return hipGetLastError();                                                                 \
+    } while (0)
+    if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2>);
+    else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2>);
+    else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2>);
+#undef IRIS_S3_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace s3
+}  // namespace iris

@@ -33,6 +33,7 @@ struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on th
     size_t w_floats = 0;                              // packed size
     size_t ref_w_floats = 0;                          // size in the reference layout
     size_t w16_off = 0, w16_halfs = 0;                // bf16 path: offset/size (bf16 elements) in blob16
+    size_t ws3_off = 0;                               // split path: offset (bf16 elements) of the hi plane in blob_s3
 };
 
 struct Stage {
@@ -54,6 +55,7 @@ struct iris_hifigan_handle {
     unsigned* tile_counters = nullptr;  // device: one next-tile counter per MRF launch of a forward (zeroed per forward)
     uint16_t* blob16 = nullptr;  // device: packed bf16 weights (biases stay fp32 in `blob`)
     size_t blob16_halfs = 0;
+    uint16_t* blob_s3 = nullptr; // device: hi/mid bf16 planes of the ResBlock conv weights (split-product mode), or null
     int hop = 1;
     int device = 0;
     // profiling
@@ -128,5 +130,13 @@ int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host);   // pac
 uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T);
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
                  void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream);
+
+// ---- fp32 storage with split-bf16 products for the ResBlock convs (conv_mfma_f32s.h; iris_hifigan_bf16.hip) ----
+int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob_s3 (null if unsupported)
+// one grouped MRF step (all branches): x/res/y pointers per branch as in the fp32 path
+struct F32sStep { const float* x[IRIS_HIFIGAN_MAX_KERNELS]; const float* res[IRIS_HIFIGAN_MAX_KERNELS];
+                  float* y[IRIS_HIFIGAN_MAX_KERNELS]; const ConvLayer* layer[IRIS_HIFIGAN_MAX_KERNELS]; };
+bool f32s_step_applicable(const iris_hifigan_handle* h, int C, int L, int nk);
+int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, int L, int C, hipStream_t stream);
 
 }  // namespace iris

@@ -223,7 +223,8 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
                     "weight upload failed: %s", hipGetErrorString(e));
     }
     if (hipMalloc(&h->tile_counters, 256 * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
-    const int rc16 = bf16_build_blob(h, weights_host);
+    int rc16 = bf16_build_blob(h, weights_host);
+    if (rc16 == IRIS_HIFIGAN_OK) rc16 = f32s_build_blob(h, weights_host);
     if (rc16 != IRIS_HIFIGAN_OK) {
         (void)hipFree(h->blob);
         delete h;
@@ -238,6 +239,7 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     if (h->blob) (void)hipFree(h->blob);
     if (h->blob16) (void)hipFree(h->blob16);
+    if (h->blob_s3) (void)hipFree(h->blob_s3);
     if (h->tile_counters) (void)hipFree(h->tile_counters);
     delete h;
     return IRIS_HIFIGAN_OK;
@@ -254,7 +256,8 @@ int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, in
     if (!h || !bytes) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     if (dtype == IRIS_HIFIGAN_BF16) { *bytes = bf16_workspace_bytes(h, B, T); return IRIS_HIFIGAN_OK; }
-    if (dtype != IRIS_HIFIGAN_F32) return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_F32_SPLIT)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     *bytes = ws_layout(h, B, T).total * sizeof(float);
     return IRIS_HIFIGAN_OK;
 }
@@ -284,8 +287,10 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                              void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
                              int32_t dtype, void* stream_) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
-    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16)
+    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16 && dtype != IRIS_HIFIGAN_F32_SPLIT)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
     if (!mel_dev || !wav_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
@@ -388,7 +393,18 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 static const int use_mrf = [] { const char* e = getenv("IRIS_HIFIGAN_MRF"); return e ? atoi(e) : 1; }();
                 static const int use_sum = [] { const char* e = getenv("IRIS_HIFIGAN_MRFSUM"); return e ? atoi(e) : 1; }();
                 bool launched = false;
-                if (use_mrf && use_sum && m == nd - 1 && half == 1 && nk == 3) {
+                if (dtype == IRIS_HIFIGAN_F32_SPLIT && f32s_step_applicable(h, st.C, L_out, nk)) {
+                    // fp32 storage, split-bf16 products (conv_mfma_f32s.h); the branch mean is left to the consumer
+                    F32sStep step;
+                    for (int j = 0; j < nk; ++j) {
+                        step.x[j] = a.p[j].x; step.res[j] = a.p[j].res; step.y[j] = a.p[j].y;
+                        step.layer[j] = half == 0 ? &st.c1[j][m] : &st.c2[j][m];
+                    }
+                    TRY(f32s_launch_step(h, step, nk, B, L_out, st.C, stream));
+                    launched = true;
+                    if (m == nd - 1 && half == 1) prev_summed = false;
+                }
+                if (!launched && use_mrf && use_sum && m == nd - 1 && half == 1 && nk == 3) {
                     // last step of the stage: the MRF kernel can form mean_j(y_j) itself.  It processes
                     // p[2], p[1], p[0]; passing the branches reversed makes that resblock 0, 1, 2 -- the
                     // reference's summation order (hifigan_pretrained.py:131-137).  The mean goes to y[0]

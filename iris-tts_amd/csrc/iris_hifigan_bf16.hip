@@ -6,6 +6,7 @@
 // The MRF mean is formed by the consumer of a stage while it stages its input (SURVEY.md 8d accounting L).
 #include "generator_internal.h"
 #include "conv_mfma_bf16.h"
+#include "conv_mfma_f32s.h"
 
 namespace iris {
 
@@ -72,6 +73,57 @@ int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host) {
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "bf16 weight upload failed: %s", hipGetErrorString(e));
     }
+    return IRIS_HIFIGAN_OK;
+}
+
+// ---- split-product mode: hi/mid planes of every ResBlock conv -------------------------------------------
+int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host) {
+    h->blob_s3 = nullptr;
+    for (const auto& st : h->stages)
+        if (st.C < 32 || (st.C & 31)) return IRIS_HIFIGAN_OK;          // mode unavailable for this config
+    size_t off = 0;
+    for (auto& st : h->stages)
+        for (size_t j = 0; j < st.c1.size(); ++j)
+            for (int half = 0; half < 2; ++half)
+                for (auto& l : (half == 0 ? st.c1[j] : st.c2[j])) {
+                    l.ws3_off = off;
+                    off += (2 * s3::packed_plane_halfs(l.C_in, l.C_out, l.k) + 127) & ~(size_t)127;
+                }
+    std::vector<uint16_t> host(off, 0);
+    const float* src = weights_host;
+    for_each_layer(h, [&](ConvLayer& l) {
+        if (l.kind == 0 && &l != &h->pre) s3::pack_conv1d_split(src, l.C_in, l.C_out, l.k, host.data() + l.ws3_off);
+        src += l.ref_w_floats + l.C_out;
+    });
+    hipError_t e = hipMalloc(&h->blob_s3, off * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(h->blob_s3, host.data(), off * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->blob_s3) (void)hipFree(h->blob_s3);
+        h->blob_s3 = nullptr;
+        return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
+                    "split-product weight upload failed: %s", hipGetErrorString(e));
+    }
+    return IRIS_HIFIGAN_OK;
+}
+
+bool f32s_step_applicable(const iris_hifigan_handle* h, int C, int L, int nk) {
+    if (!h->blob_s3 || nk > s3::kMaxGroup) return false;
+    s3::Launch a; memset(&a, 0, sizeof(a));
+    a.C = C; a.L = L;
+    return s3::applicable(a, nk);
+}
+
+int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, int L, int C, hipStream_t stream) {
+    s3::Launch a; memset(&a, 0, sizeof(a));
+    for (int j = 0; j < nk; ++j) {
+        const ConvLayer& l = *st.layer[j];
+        s3::Problem& p = a.p[j];
+        p.x = st.x[j]; p.res = st.res[j]; p.y = st.y[j];
+        p.wp = h->blob_s3 + l.ws3_off; p.bias = h->blob + l.b_off;
+        p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
+    }
+    a.B = B; a.L = L; a.C = C; a.slope = h->cfg.lrelu_slope;
+    HIP_TRY(s3::launch(a, nk, stream));
     return IRIS_HIFIGAN_OK;
 }
 
@@ -226,6 +278,29 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
     a.B = B; a.L_in = L; a.L_out = L; a.C_in = C_in; a.C_out = C_out; a.n_idx = L;
     a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
     HIP_TRY(launch_conv_bf16(a, 1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,
+                                    float* y_dev, int32_t B, int32_t L, int32_t C, int32_t k, int32_t dilation, float slope,
+                                    void* stream_) {
+    using namespace iris;
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C < 1 || k < 1 || !(k & 1) || dilation < 1 || B > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv1d shape");
+    s3::Launch a; memset(&a, 0, sizeof(a));
+    a.B = B; a.L = L; a.C = C; a.slope = slope;
+    if (!s3::applicable(a, 1)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product conv needs C %% 32 == 0");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<uint16_t> packed(2 * s3::packed_plane_halfs(C, C, k));
+    s3::pack_conv1d_split(w_host, C, C, k, packed.data());
+    DevBytes wb, bb;
+    HIP_TRY(wb.upload(packed.data(), packed.size() * sizeof(uint16_t)));
+    HIP_TRY(bb.upload(bias_host, sizeof(float) * C));
+    a.p[0].x = x_dev; a.p[0].wp = wb.p; a.p[0].bias = (const float*)bb.p; a.p[0].res = res_dev; a.p[0].y = y_dev;
+    a.p[0].ks = k; a.p[0].dil = dilation; a.p[0].pad_left = dilation * (k - 1) / 2;
+    HIP_TRY(s3::launch(a, 1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
 }

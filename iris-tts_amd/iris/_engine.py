@@ -18,7 +18,7 @@ from . import _native
 from ._weights import GeneratorConfig, expected_weight_count, weight_blob
 
 KIND_NAMES = {0: "conv_pre", 1: "upsample", 2: "mrf_resblock_conv", 3: "conv_post"}
-DTYPES = {"f32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16}
+DTYPES = {"f32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16, "f32s": _native.DTYPE_F32_SPLIT}
 
 
 def _dtype_code(dtype: str) -> int:
