@@ -51,6 +51,10 @@ struct Launch {
     int nz;               // problems interleaved along blockIdx.x
     int n_co_blk, Qp, n_ct;
     unsigned plane_bytes[kMaxGroup];   // bytes of one weight plane of problem j (= ks * Qp * n_ct * 1024)
+    float* sum_y;         // set: last conv step of a stage -- a block runs ALL nz branches of its tile in the order
+                          // 0, 1, .. (the reference's summation order, hifigan_pretrained.py:131-137) and stores only
+                          // their mean here; the per-branch outputs are not written
+    float sum_div;        // nz as float
 };
 
 // Rows [in_row0, in_row0 + R) x channels [c0, c0 + CIC) of LeakyReLU(x) -> two bf16 planes in LDS.
@@ -96,7 +100,7 @@ __device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, 
     }
 }
 
-template <int WT, int WC, int MT, int NT, int CIC, int MINB>
+template <int WT, int WC, int MT, int NT, int CIC, int MINB, bool ZS>
 __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch a) {
     extern __shared__ __attribute__((aligned(16))) char lds_s3[];
     char* lds = lds_s3;
@@ -110,17 +114,25 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
     const int wt = wave / WC, wc = wave - wt * WC;
     const int lo = lane & 31, hi = lane >> 5;
 
-    // blockIdx.x -> (time tile, branch z heaviest first, C_out block)
+    // blockIdx.x -> (time tile, branch z heaviest first, C_out block); ZS: (time tile, C_out block), all branches here
     const int sub = blockIdx.x % a.n_co_blk, item = blockIdx.x / a.n_co_blk;
-    const int zr = item % a.nz, tile_t = item / a.nz;
-    const int z = a.nz - 1 - zr;
+    const int nzp = ZS ? 1 : a.nz;
+    const int zr = item % nzp, tile_t = item / nzp;
+    const int b = blockIdx.y;
+    const int i0 = tile_t * T_BLK;
+    constexpr int RS = NT * 32 * 4 + 16;
+    constexpr int PPRO = NT * 8;                       // 16-byte fp32 pieces per row of this wave's channel span
+    constexpr int NP = 4 * NT;                         // pieces per lane and 32-row m-tile
+    f32x4 msum[ZS ? MT : 1][ZS ? NP : 1];              // ZS: running sum of the branch outputs, in output-piece layout
+    const int n_pass = ZS ? a.nz : 1;
+  for (int zi = 0; zi < n_pass; ++zi) {
+    const int z = ZS ? zi : a.nz - 1 - zr;
     Problem p = a.p[0];
     unsigned plane_bytes = a.plane_bytes[0];
     if (z == 1) { p = a.p[1]; plane_bytes = a.plane_bytes[1]; }
     if (z == 2) { p = a.p[2]; plane_bytes = a.plane_bytes[2]; }
     if (z == 3) { p = a.p[3]; plane_bytes = a.plane_bytes[3]; }
-    const int b = blockIdx.y;
-    const int i0 = tile_t * T_BLK;
+    if (ZS && zi > 0) __syncthreads();               // the previous branch's scratch reads are done
     const int ks = p.ks;
     const int span = (ks - 1) * p.dil;
     const int R = T_BLK + span;
@@ -206,13 +218,10 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
     // Epilogue: (acc + bias) -> per-wave fp32 scratch [row][channel] -> 16-byte pieces (4 channels of one row), + residual,
     // coalesced fp32 stores.  The scratch aliases the window: every wave must be done with it first.
     __syncthreads();
-    constexpr int RS = NT * 32 * 4 + 16;
-    constexpr int PPRO = NT * 8;                       // 16-byte fp32 pieces per row of this wave's channel span
-    constexpr int NP = 4 * NT;                         // pieces per lane and 32-row m-tile
     char* const scr = lds + wave * (32 * RS);
     const unsigned tensor_bytes = (unsigned)a.L * (unsigned)a.C * 4u;
     const size_t ob = (size_t)b * a.L * a.C;
-    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + ob, tensor_bytes);
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc((ZS ? a.sum_y : p.y) + ob, tensor_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, p.res ? tensor_bytes : 0u);
     unsigned pv[NP];
     int pscr[NP];
@@ -253,13 +262,20 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned rw = resv[j][e];
-                const float o = v[e] + __builtin_bit_cast(float, rw);
+                float o = v[e] + __builtin_bit_cast(float, rw);
+                if constexpr (ZS) {
+                    o = zi == 0 ? o : msum[m][j][e] + o;          // xs = r0; xs += r1; xs += r2
+                    msum[m][j][e] = o;
+                    if (zi == n_pass - 1) o = o / a.sum_div;      // true division, hifigan_pretrained.py:137
+                }
                 outp[j][e] = __builtin_bit_cast(unsigned, o);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!ZS || zi == n_pass - 1) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)pv[j], (int)msoff, 0);
+            for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)pv[j], (int)msoff, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // store data stays live until every store of the group has issued (store-data note in mrf_conv_mfma_f32.h)
 #pragma unroll
@@ -267,6 +283,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -325,7 +342,9 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
     const size_t lds_bytes = window > scratch ? window : scratch;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int n_t = (a.L + t.T_BLK - 1) / t.T_BLK;
-    dim3 grid((unsigned)(n_t * nz * a.n_co_blk), (unsigned)a.B, 1u), block(256);
+    const bool zs = a.sum_y != nullptr;
+    a.sum_div = (float)nz;
+    dim3 grid((unsigned)(n_t * (zs ? 1 : nz) * a.n_co_blk), (unsigned)a.B, 1u), block(256);
 #define IRIS_S3_LAUNCH(...)                                                                       \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
@@ -338,9 +357,14 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
         return hipGetLastError();                                                                 \
     } while (0)
-    if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2>);
-    else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2>);
-    else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2>);
+    if (zs) {
+        if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2, true>);
+        else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2, true>);
+        else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2, true>);
+    }
+    if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2, false>);
+    else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2, false>);
+    else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2, false>);
 #undef IRIS_S3_LAUNCH
     return hipErrorInvalidValue;
 }

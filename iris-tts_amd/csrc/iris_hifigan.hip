@@ -400,9 +400,13 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                         step.x[j] = a.p[j].x; step.res[j] = a.p[j].res; step.y[j] = a.p[j].y;
                         step.layer[j] = half == 0 ? &st.c1[j][m] : &st.c2[j][m];
                     }
-                    TRY(f32s_launch_step(h, step, nk, B, L_out, st.C, stream));
+                    // last step of the stage: the kernel folds the branch mean (written to y[0]; a lane overwrites only
+                    // elements it has read itself as branch 0's residual)
+                    static const int s3_sum = [] { const char* e = getenv("IRIS_HIFIGAN_S3SUM"); return e ? atoi(e) : 1; }();
+                    const bool fold = s3_sum && m == nd - 1 && half == 1;
+                    TRY(f32s_launch_step(h, step, nk, B, L_out, st.C, fold ? ws + w.y[0] : nullptr, stream));
                     launched = true;
-                    if (m == nd - 1 && half == 1) prev_summed = false;
+                    if (m == nd - 1 && half == 1) prev_summed = fold;
                 }
                 if (!launched && use_mrf && use_sum && m == nd - 1 && half == 1 && nk == 3) {
                     // last step of the stage: the MRF kernel can form mean_j(y_j) itself.  It processes

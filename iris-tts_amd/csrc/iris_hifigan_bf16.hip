@@ -113,7 +113,7 @@ bool f32s_step_applicable(const iris_hifigan_handle* h, int C, int L, int nk) {
     return s3::applicable(a, nk);
 }
 
-int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, int L, int C, hipStream_t stream) {
+int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, int L, int C, float* sum_y, hipStream_t stream) {
     s3::Launch a; memset(&a, 0, sizeof(a));
     for (int j = 0; j < nk; ++j) {
         const ConvLayer& l = *st.layer[j];
@@ -122,7 +122,7 @@ int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, 
         p.wp = h->blob_s3 + l.ws3_off; p.bias = h->blob + l.b_off;
         p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
     }
-    a.B = B; a.L = L; a.C = C; a.slope = h->cfg.lrelu_slope;
+    a.B = B; a.L = L; a.C = C; a.slope = h->cfg.lrelu_slope; a.sum_y = sum_y;
     HIP_TRY(s3::launch(a, nk, stream));
     return IRIS_HIFIGAN_OK;
 }
