@@ -73,9 +73,10 @@ def cpu_baseline(cfg, sd, mel, budget_s=20.0):
     times, t_start = [], time.perf_counter()
     while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
         t0 = time.perf_counter()
-        orc.generator_forward_torch(folded, x)
+        out_ref = orc.generator_forward_torch(folded, x)
         times.append(time.perf_counter() - t0)
     best = statistics.median(times)
+    cpu_baseline.last_output = out_ref.numpy()[:, 0, :]       # the checker's waveform of this mel (parity of the GPU modes)
     samples = mel.shape[0] * mel.shape[2] * 256
     return {"value": samples / best, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} full forward(s) of the same B={mel.shape[0]} x 80 x {mel.shape[2]} mel after one "
@@ -253,6 +254,28 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, mel_np)
+        # Beside the headline (outside its timed region): the same workload in the other arithmetic modes of the
+        # library, each with its max-abs distance to the CPU checker's waveform.  `value` above is always --dtype.
+        ref = cpu_baseline.last_output
+        modes = []
+        for mode in ("f32", "f32s", "bf16"):
+            try:
+                for _ in range(2):
+                    w = eng.forward(mel, dtype=mode)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    w = eng.forward(mel, dtype=mode)
+                torch.cuda.synchronize(dev)
+                dt = (time.perf_counter() - t0) / 10
+                modes.append({"dtype": mode, "ms_per_step": 1e3 * dt, "value": B * T * eng.hop_length / dt, "unit": "samples/s",
+                              "max_abs_err_vs_cpu_checker": float(np.abs(w.cpu().numpy() - ref).max()),
+                              "note": {"f32": "exact fp32 MFMA (the parity path; no launch events here)",
+                                       "f32s": "fp32 storage/accumulate, split-bf16 products in the ResBlock convs (opt-in)",
+                                       "bf16": "bf16 storage, fp32 accumulate (opt-in; tolerance unpinned by the reference)"}[mode]})
+            except Exception as exc:      # a mode the configuration does not support
+                modes.append({"dtype": mode, "error": str(exc)})
+        out["other_modes"] = modes
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
