@@ -325,7 +325,7 @@ inline bool applicable(const Launch& a, int nz) {
 }
 
 inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
-    const Tile t = pick_tile(a.C);
+    Tile t = pick_tile(a.C);
     a.n_co_blk = a.C / t.CO_BLK;
     a.Qp = b16::packed_qsteps(a.C);
     a.n_ct = b16::packed_cotiles(a.C);
@@ -336,14 +336,21 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
         if (s > span) span = s;
         a.plane_bytes[j] = (unsigned)(packed_plane_halfs(a.C, a.C, a.p[j].ks) * 2);
     }
+    const bool zs = a.sum_y != nullptr;
+    a.sum_div = (float)nz;
+    // small grids (short utterances at batch 1): a launch lasts as long as its longest block, so the tile height is
+    // halved when the grid has fewer than 2.5 blocks per CU (measured: 1.05 -> 0.88 ms at T = 100)
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
+                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int mt_env = b16::env_int("IRIS_S3_MT", 0);
+    const long long blocks2 = (long long)((a.L + t.T_BLK - 1) / t.T_BLK) * (zs ? 1 : nz) * a.n_co_blk * a.B;
+    if (mt_env ? mt_env == 1 : 2 * blocks2 < 5LL * n_cu) { t.MT = 1; t.T_BLK = t.WT * 32; }
     const int SB = t.CIC * 2 + 16;
     const size_t window = 2 * (size_t)(t.T_BLK + span) * SB;
     const size_t scratch = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);
     const size_t lds_bytes = window > scratch ? window : scratch;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int n_t = (a.L + t.T_BLK - 1) / t.T_BLK;
-    const bool zs = a.sum_y != nullptr;
-    a.sum_div = (float)nz;
     dim3 grid((unsigned)(n_t * (zs ? 1 : nz) * a.n_co_blk), (unsigned)a.B, 1u), block(256);
 #define IRIS_S3_LAUNCH(...)                                                                       \
     do {                                                                                          \
@@ -357,14 +364,17 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
         return hipGetLastError();                                                                 \
     } while (0)
-    if (zs) {
-        if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2, true>);
-        else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2, true>);
-        else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2, true>);
+#define IRIS_S3_CASE(WT_, WC_, NT_, CIC_)                                                         \
+    if (t.WT == WT_ && t.WC == WC_ && t.NT == NT_) {                                              \
+        if (zs) { if (t.MT == 1) IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<WT_, WC_, 1, NT_, CIC_, 2, true>);    \
+                  else           IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<WT_, WC_, 2, NT_, CIC_, 2, true>); }  \
+        else    { if (t.MT == 1) IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<WT_, WC_, 1, NT_, CIC_, 2, false>);   \
+                  else           IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<WT_, WC_, 2, NT_, CIC_, 2, false>); } \
     }
-    if (t.WT == 4)       IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<4, 1, 2, 1, 32, 2, false>);
-    else if (t.NT == 1)  IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 1, 64, 2, false>);
-    else                 IRIS_S3_LAUNCH(conv_mfma_f32s_kernel<2, 2, 2, 2, 64, 2, false>);
+    IRIS_S3_CASE(4, 1, 1, 32)
+    IRIS_S3_CASE(2, 2, 1, 64)
+    IRIS_S3_CASE(2, 2, 2, 64)
+#undef IRIS_S3_CASE
 #undef IRIS_S3_LAUNCH
     return hipErrorInvalidValue;
 }
