@@ -165,6 +165,11 @@ int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_
 int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,
                                     float* y_dev, int32_t B, int32_t L, int32_t C, int32_t k, int32_t dilation, float slope,
                                     void* stream);
+/* LeakyReLU + ConvTranspose1d(C_in -> C_out, k, stride u, padding (k-u)/2) on fp32 tensors with split-bf16 products
+ * (the upsamplers in dtype IRIS_HIFIGAN_F32_SPLIT): hifigan_pretrained.py:100-108,127-128. */
+int32_t iris_hifigan_op_conv_transpose1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, float* y_dev,
+                                              int32_t B, int32_t L, int32_t C_in, int32_t C_out, int32_t k, int32_t u,
+                                              float slope, void* stream);
 
 /* ---- PostNet, the layer in front of the vocoder --------------------------
  * Replaces `postnet(mel_bt_f, training=False)` (scripts/synthesize.py:148-166; model src/iris/postnet.py:48-67):

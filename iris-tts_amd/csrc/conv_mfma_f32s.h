@@ -51,6 +51,14 @@ struct Launch {
     int nz;               // problems interleaved along blockIdx.x
     int n_co_blk, Qp, n_ct;
     unsigned plane_bytes[kMaxGroup];   // bytes of one weight plane of problem j (= ks * Qp * n_ct * 1024)
+    // ConvTranspose1d as u phase convolutions (conv_mfma_f32.h): all zero for a plain Conv1d
+    int C_in;             // input channels (0: = C)
+    int L_in;             // input rows (0: = L); L is then the OUTPUT length u * L_in
+    int n_idx;            // output row-indices per phase (0: = L)
+    int out_stride;       // output row o = i * out_stride + out_off + phase   (0: stride 1, offset 0)
+    int out_off;
+    int z_is_phase;       // the z part of blockIdx.x is the phase of problem 0; its weights start phase_bytes further per phase
+    unsigned phase_bytes;
     float* sum_y;         // set: last conv step of a stage -- a block runs ALL nz branches of its tile in the order
                           // 0, 1, .. (the reference's summation order, hifigan_pretrained.py:131-137) and stores only
                           // their mean here; the per-branch outputs are not written
@@ -64,8 +72,9 @@ __device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, 
     constexpr int SB = CIC * 2 + 16;
     constexpr int PPR = CIC / 4;          // 16-byte fp32 pieces (4 channels) per row
     const int tid = threadIdx.x;
-    const unsigned tensor_bytes = (unsigned)a.L * (unsigned)a.C * 4u;
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (size_t)b * a.L * a.C, tensor_bytes);
+    const int Lin = a.L_in ? a.L_in : a.L, Cin = a.C_in ? a.C_in : a.C;
+    const unsigned tensor_bytes = (unsigned)Lin * (unsigned)Cin * 4u;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + (size_t)b * Lin * Cin, tensor_bytes);
     const int total = R * PPR;
     constexpr int U = 4;
     for (int base = 0; base < total; base += 256 * U) {
@@ -75,8 +84,8 @@ __device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, 
             const int idx = base + u * 256 + tid;
             const int r = idx / PPR, pc = idx - r * PPR;
             const int row = in_row0 + r;
-            const bool ok = idx < total && row >= 0 && row < a.L;
-            v[u] = buf_load4(xr, ok ? (unsigned)(row * a.C + c0 + 4 * pc) * 4u : kOob, 0);
+            const bool ok = idx < total && row >= 0 && row < Lin;
+            v[u] = buf_load4(xr, ok ? (unsigned)(row * Cin + c0 + 4 * pc) * 4u : kOob, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -126,12 +135,17 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
     f32x4 msum[ZS ? MT : 1][ZS ? NP : 1];              // ZS: running sum of the branch outputs, in output-piece layout
     const int n_pass = ZS ? a.nz : 1;
   for (int zi = 0; zi < n_pass; ++zi) {
-    const int z = ZS ? zi : a.nz - 1 - zr;
+    const int z = ZS ? zi : (a.z_is_phase ? zr : a.nz - 1 - zr);
     Problem p = a.p[0];
     unsigned plane_bytes = a.plane_bytes[0];
-    if (z == 1) { p = a.p[1]; plane_bytes = a.plane_bytes[1]; }
-    if (z == 2) { p = a.p[2]; plane_bytes = a.plane_bytes[2]; }
-    if (z == 3) { p = a.p[3]; plane_bytes = a.plane_bytes[3]; }
+    if (!a.z_is_phase) {
+        if (z == 1) { p = a.p[1]; plane_bytes = a.plane_bytes[1]; }
+        if (z == 2) { p = a.p[2]; plane_bytes = a.plane_bytes[2]; }
+        if (z == 3) { p = a.p[3]; plane_bytes = a.plane_bytes[3]; }
+    }
+    const int Cin = a.C_in ? a.C_in : a.C;
+    const int ostride = a.out_stride ? a.out_stride : 1;
+    const int ooff = a.out_off + (a.z_is_phase ? z : 0);
     if (ZS && zi > 0) __syncthreads();               // the previous branch's scratch reads are done
     const int ks = p.ks;
     const int span = (ks - 1) * p.dil;
@@ -151,13 +165,14 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
 
     const unsigned q_bytes = (unsigned)a.n_ct * 1024u;
     const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, 2u * plane_bytes);
+    const unsigned phase_off = a.z_is_phase ? (unsigned)z * a.phase_bytes : 0u;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc((const char*)p.wp + phase_off, plane_bytes + (unsigned)ks * tap_bytes);
     const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
     const int a_off = (wt * MT * 32 + lo) * SB + hi * 16;
     const int dil_bytes = p.dil * SB;
     const int NG = ks * QPC;
 
-    for (int c0 = 0; c0 < a.C; c0 += CIC) {
+    for (int c0 = 0; c0 < Cin; c0 += CIC) {
         if (c0 > 0) __syncthreads();
         stage_window<CIC>(a, p, lds_hi, lds_mid, b, in_row0, R, c0);
         __syncthreads();
@@ -230,7 +245,8 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
         const int q = j * 64 + lane;
         const int row_l = q / PPRO, pc = q - row_l * PPRO;
         pscr[j] = row_l * RS + pc * 16;
-        pv[j] = (unsigned)((i0 + wt * MT * 32 + row_l) * a.C + ct0 * 32 + 4 * pc) * 4u;    // rows >= L exceed num_records
+        // output row o = i * stride + offset: rows < 0 wrap to >= 2^31 and rows >= L exceed num_records (both dropped)
+        pv[j] = (unsigned)(((i0 + wt * MT * 32 + row_l) * ostride + ooff) * a.C + ct0 * 32 + 4 * pc) * 4u;
     }
     f32x4 bias4[NT][4];
 #pragma unroll
@@ -239,7 +255,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
         for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (ct0 + nt) * 32 + 8 * g + 4 * hi);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const unsigned msoff = (unsigned)(m * 32 * a.C) * 4u;
+        const unsigned msoff = (unsigned)(m * 32 * ostride * a.C) * 4u;
         u32x4 resv[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) resv[j] = buf_load4(rr, pv[j], msoff);
@@ -304,6 +320,23 @@ inline void pack_conv1d_split(const float* w, int C_in, int C_out, int ks, uint1
     b16::pack_conv1d_bf16(mid.data(), C_in, C_out, ks, out + packed_plane_halfs(C_in, C_out, ks));
 }
 
+// ConvTranspose1d weights [C_in][C_out][k]: all phases of the hi plane, then all phases of the mid plane
+inline size_t packed_convt_plane_halfs(int C_in, int C_out, int k, int u) { return b16::packed_convt_phase_halfs(C_in, C_out, k, u) * u; }
+inline void pack_convt_split(const float* w, int C_in, int C_out, int k, int u, uint16_t* out) {
+    const size_t n = (size_t)C_in * C_out * k;
+    std::vector<float> hi(n), mid(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t h = b16::f32_to_bf16(w[i]);
+        uint32_t bits = (uint32_t)h << 16;
+        float hf;
+        memcpy(&hf, &bits, 4);
+        hi[i] = hf;
+        mid[i] = w[i] - hf;
+    }
+    b16::pack_convt_bf16(hi.data(), C_in, C_out, k, u, out);
+    b16::pack_convt_bf16(mid.data(), C_in, C_out, k, u, out + packed_convt_plane_halfs(C_in, C_out, k, u));
+}
+
 struct Tile { int WT, WC, MT, NT, CIC, MINB, T_BLK, CO_BLK; };
 inline Tile pick_tile(int C) {
     Tile t;
@@ -317,24 +350,28 @@ inline Tile pick_tile(int C) {
 }
 
 inline bool applicable(const Launch& a, int nz) {
-    if (nz < 1 || nz > kMaxGroup || a.C < 32 || (a.C & 31)) return false;
+    if (nz < 1 || (!a.z_is_phase && nz > kMaxGroup) || a.C < 32 || (a.C & 31)) return false;
     const Tile t = pick_tile(a.C);
-    if (a.C % t.CIC || a.C % t.CO_BLK) return false;
-    if ((double)a.L * a.C * 4.0 >= 2147483648.0 - 4194304.0) return false;       // 32-bit buffer offsets
+    const int Cin = a.C_in ? a.C_in : a.C, Lin = a.L_in ? a.L_in : a.L;
+    if (Cin % t.CIC || a.C % t.CO_BLK) return false;
+    if ((double)a.L * a.C * 4.0 >= 2147483648.0 - 4194304.0 || (double)Lin * Cin * 4.0 >= 2147483648.0 - 4194304.0)
+        return false;                                                            // 32-bit buffer offsets
     return true;
 }
 
 inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
     Tile t = pick_tile(a.C);
     a.n_co_blk = a.C / t.CO_BLK;
-    a.Qp = b16::packed_qsteps(a.C);
+    const int Cin = a.C_in ? a.C_in : a.C;
+    const int n_rows = a.n_idx ? a.n_idx : a.L;
+    a.Qp = b16::packed_qsteps(Cin);
     a.n_ct = b16::packed_cotiles(a.C);
     a.nz = nz;
     int span = 0;
-    for (int j = 0; j < nz; ++j) {
+    for (int j = 0; j < (a.z_is_phase ? 1 : nz); ++j) {
         const int s = (a.p[j].ks - 1) * a.p[j].dil;
         if (s > span) span = s;
-        a.plane_bytes[j] = (unsigned)(packed_plane_halfs(a.C, a.C, a.p[j].ks) * 2);
+        if (!a.z_is_phase) a.plane_bytes[j] = (unsigned)(packed_plane_halfs(a.C, a.C, a.p[j].ks) * 2);   // (phases: set by the caller)
     }
     const bool zs = a.sum_y != nullptr;
     a.sum_div = (float)nz;
@@ -343,14 +380,14 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
                                  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     static const int mt_env = b16::env_int("IRIS_S3_MT", 0);
-    const long long blocks2 = (long long)((a.L + t.T_BLK - 1) / t.T_BLK) * (zs ? 1 : nz) * a.n_co_blk * a.B;
+    const long long blocks2 = (long long)((n_rows + t.T_BLK - 1) / t.T_BLK) * (zs ? 1 : nz) * a.n_co_blk * a.B;
     if (mt_env ? mt_env == 1 : 2 * blocks2 < 5LL * n_cu) { t.MT = 1; t.T_BLK = t.WT * 32; }
     const int SB = t.CIC * 2 + 16;
     const size_t window = 2 * (size_t)(t.T_BLK + span) * SB;
     const size_t scratch = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);
     const size_t lds_bytes = window > scratch ? window : scratch;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    const int n_t = (a.L + t.T_BLK - 1) / t.T_BLK;
+    const int n_t = (n_rows + t.T_BLK - 1) / t.T_BLK;
     dim3 grid((unsigned)(n_t * (zs ? 1 : nz) * a.n_co_blk), (unsigned)a.B, 1u), block(256);
 #define IRIS_S3_LAUNCH(...)                                                                       \
     do {                                                                                          \

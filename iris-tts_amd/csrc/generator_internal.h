@@ -137,6 +137,8 @@ int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host);   // pac
 struct F32sStep { const float* x[IRIS_HIFIGAN_MAX_KERNELS]; const float* res[IRIS_HIFIGAN_MAX_KERNELS];
                   float* y[IRIS_HIFIGAN_MAX_KERNELS]; const ConvLayer* layer[IRIS_HIFIGAN_MAX_KERNELS]; };
 bool f32s_step_applicable(const iris_hifigan_handle* h, int C, int L, int nk);
+bool f32s_ups_applicable(const iris_hifigan_handle* h, const ConvLayer& l, int L_in);
+int f32s_launch_ups(iris_hifigan_handle* h, const ConvLayer& l, const float* x, float* y, int B, int L_in, hipStream_t stream);
 // sum_y: when set, the step stores only the mean of the branch outputs there (last conv step of a stage)
 int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, int L, int C, float* sum_y, hipStream_t stream);
 

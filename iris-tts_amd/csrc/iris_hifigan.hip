@@ -362,7 +362,14 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
             TRY(prof.begin(1, (int)i, 0, 2.0 * fB * L * l.C_in * l.C_out * l.k,
                            4.0 * (fB * L * l.C_in * n_in + fB * L_out * l.C_out +
                                   (double)l.ref_w_floats + l.C_out)));
-            HIP_TRY(launch_conv(a, l.u, stream));
+            // split-product mode: single-input upsamplers (conv_pre output, or the folded branch mean) on split products
+            // (off by default: with the upsamplers split as well the worst observed waveform error grows from 2e-5 to
+            //  5e-5 -- still inside 1e-4, but the mode keeps the wider margin unless IRIS_HIFIGAN_S3UPS=1)
+            static const int s3_ups = [] { const char* e = getenv("IRIS_HIFIGAN_S3UPS"); return e ? atoi(e) : 0; }();
+            if (s3_ups && dtype == IRIS_HIFIGAN_F32_SPLIT && a.in_act == IN_ACT_LRELU && f32s_ups_applicable(h, l, L))
+                TRY(f32s_launch_ups(h, l, a.p[0].x, a.p[0].y, B, L, stream));
+            else
+                HIP_TRY(launch_conv(a, l.u, stream));
             TRY(prof.end());
         }
         // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----

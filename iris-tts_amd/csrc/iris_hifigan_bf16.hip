@@ -82,17 +82,21 @@ int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host) {
     for (const auto& st : h->stages)
         if (st.C < 32 || (st.C & 31)) return IRIS_HIFIGAN_OK;          // mode unavailable for this config
     size_t off = 0;
-    for (auto& st : h->stages)
+    for (auto& st : h->stages) {
+        st.up.ws3_off = off;
+        off += (2 * s3::packed_convt_plane_halfs(st.up.C_in, st.up.C_out, st.up.k, st.up.u) + 127) & ~(size_t)127;
         for (size_t j = 0; j < st.c1.size(); ++j)
             for (int half = 0; half < 2; ++half)
                 for (auto& l : (half == 0 ? st.c1[j] : st.c2[j])) {
                     l.ws3_off = off;
                     off += (2 * s3::packed_plane_halfs(l.C_in, l.C_out, l.k) + 127) & ~(size_t)127;
                 }
+    }
     std::vector<uint16_t> host(off, 0);
     const float* src = weights_host;
     for_each_layer(h, [&](ConvLayer& l) {
         if (l.kind == 0 && &l != &h->pre) s3::pack_conv1d_split(src, l.C_in, l.C_out, l.k, host.data() + l.ws3_off);
+        if (l.kind == 1) s3::pack_convt_split(src, l.C_in, l.C_out, l.k, l.u, host.data() + l.ws3_off);
         src += l.ref_w_floats + l.C_out;
     });
     hipError_t e = hipMalloc(&h->blob_s3, off * sizeof(uint16_t));
@@ -124,6 +128,36 @@ int f32s_launch_step(iris_hifigan_handle* h, const F32sStep& st, int nk, int B, 
     }
     a.B = B; a.L = L; a.C = C; a.slope = h->cfg.lrelu_slope; a.sum_y = sum_y;
     HIP_TRY(s3::launch(a, nk, stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+namespace {
+// LeakyReLU + ConvTranspose1d of one stage as u phase launches in one grid (split products)
+void fill_ups(s3::Launch& a, const ConvLayer& l, const float* x, const void* wp, const float* bias, float* y,
+              int B, int L_in, float slope) {
+    memset(&a, 0, sizeof(a));
+    const int taps = b16::convt_taps(l.k, l.u);
+    a.p[0].x = x; a.p[0].wp = wp; a.p[0].bias = bias; a.p[0].res = nullptr; a.p[0].y = y;
+    a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
+    a.B = B; a.L = L_in * l.u; a.C = l.C_out; a.slope = slope;
+    a.C_in = l.C_in; a.L_in = L_in; a.n_idx = L_in + taps - 1;
+    a.out_stride = l.u; a.out_off = -(l.k - l.u) / 2; a.z_is_phase = 1;
+    a.phase_bytes = (unsigned)(b16::packed_convt_phase_halfs(l.C_in, l.C_out, l.k, l.u) * 2);
+    a.plane_bytes[0] = (unsigned)(s3::packed_convt_plane_halfs(l.C_in, l.C_out, l.k, l.u) * 2);
+}
+}  // namespace
+
+bool f32s_ups_applicable(const iris_hifigan_handle* h, const ConvLayer& l, int L_in) {
+    if (!h->blob_s3 || l.kind != 1 || l.u > 65535) return false;
+    s3::Launch a;
+    fill_ups(a, l, nullptr, nullptr, nullptr, nullptr, 1, L_in, 0.f);
+    return s3::applicable(a, l.u) && (double)s3::packed_convt_plane_halfs(l.C_in, l.C_out, l.k, l.u) * 4.0 < 2147483648.0;
+}
+
+int f32s_launch_ups(iris_hifigan_handle* h, const ConvLayer& l, const float* x, float* y, int B, int L_in, hipStream_t stream) {
+    s3::Launch a;
+    fill_ups(a, l, x, h->blob_s3 + l.ws3_off, h->blob + l.b_off, y, B, L_in, h->cfg.lrelu_slope);
+    HIP_TRY(s3::launch(a, l.u, stream));
     return IRIS_HIFIGAN_OK;
 }
 
@@ -301,6 +335,29 @@ int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, con
     a.p[0].x = x_dev; a.p[0].wp = wb.p; a.p[0].bias = (const float*)bb.p; a.p[0].res = res_dev; a.p[0].y = y_dev;
     a.p[0].ks = k; a.p[0].dil = dilation; a.p[0].pad_left = dilation * (k - 1) / 2;
     HIP_TRY(s3::launch(a, 1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_conv_transpose1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, float* y_dev,
+                                              int32_t B, int32_t L, int32_t C_in, int32_t C_out, int32_t k, int32_t u,
+                                              float slope, void* stream_) {
+    using namespace iris;
+    if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || u < 1 || k < u || ((k - u) & 1) || B > 65535 || u > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_transpose1d shape");
+    ConvLayer l; l.kind = 1; l.C_in = C_in; l.C_out = C_out; l.k = k; l.u = u;
+    s3::Launch a;
+    fill_ups(a, l, nullptr, nullptr, nullptr, nullptr, B, L, slope);
+    if (!s3::applicable(a, u)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product upsample: channel counts not supported");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<uint16_t> packed(2 * s3::packed_convt_plane_halfs(C_in, C_out, k, u));
+    s3::pack_convt_split(w_host, C_in, C_out, k, u, packed.data());
+    DevBytes wb, bb;
+    HIP_TRY(wb.upload(packed.data(), packed.size() * sizeof(uint16_t)));
+    HIP_TRY(bb.upload(bias_host, sizeof(float) * C_out));
+    fill_ups(a, l, x_dev, wb.p, (const float*)bb.p, y_dev, B, L, slope);
+    HIP_TRY(s3::launch(a, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
 }

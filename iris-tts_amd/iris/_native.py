@@ -91,6 +91,7 @@ SYMBOLS = {
     "iris_hifigan_op_conv1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv_transpose1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv1d_f32s": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
+    "iris_hifigan_op_conv_transpose1d_f32s": (_i32, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_postnet_create": (_i32, [_i32, _i32, _i32, _i32, _fp, _u64, _c.POINTER(_vp)]),
     "iris_postnet_destroy": (_i32, [_vp]),
     "iris_postnet_workspace_bytes": (_i32, [_vp, _i32, _i32, _c.POINTER(_u64)]),

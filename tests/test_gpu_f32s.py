@@ -49,6 +49,25 @@ def test_f32s_conv1d_matches_oracle(B, L, C, k, d, use_res):
     assert np.abs(got - want).max() <= TOL_LAYER * np.abs(want).max()
 
 
+@pytest.mark.parametrize("B,L,Ci,Co,k,u", [(1, 40, 512, 256, 16, 8), (2, 130, 256, 128, 16, 8), (1, 300, 128, 64, 4, 2),
+                                            (2, 517, 64, 32, 4, 2), (1, 1, 64, 32, 4, 2), (1, 700, 64, 32, 4, 2)])
+def test_f32s_conv_transpose1d_matches_oracle(B, L, Ci, Co, k, u):
+    from iris import _native
+    lib = _native.load()
+    rng = np.random.default_rng(L + Ci + k)
+    x = rng.standard_normal((B, Ci, L)).astype(np.float32)
+    w = (rng.standard_normal((Ci, Co, k)) / np.sqrt(Ci * k / u)).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    want = orc.conv_transpose1d_np(orc.lrelu_np(x, 0.1), w, b, u, (k - u) // 2)
+    xd = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()
+    yd = torch.full((B, L * u, Co), float("nan"), device="cuda")
+    _native.check("op_conv_transpose1d_f32s", lib.iris_hifigan_op_conv_transpose1d_f32s(
+        xd.data_ptr(), _fp(w), _fp(b), yd.data_ptr(), B, L, Ci, Co, k, u, 0.1, None))
+    got = yd.cpu().numpy().transpose(0, 2, 1)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert np.abs(got - want).max() <= TOL_LAYER * np.abs(want).max()
+
+
 @pytest.mark.parametrize("case", ["v1_default_T4_taps", "v1_default_B2_T16", "v1_amplified_T24"])
 def test_f32s_generator_matches_reference_goldens(case, golden, case_setup, dev):
     """Against the waveform the REFERENCE produced for the same weights and mel."""
