@@ -258,9 +258,10 @@ def main():
         # library, each with its max-abs distance to the CPU checker's waveform.  `value` above is always --dtype.
         ref = cpu_baseline.last_output
         modes = []
+        time.sleep(1.0)                     # let the CPU leg's worker threads go idle (they slow the launching thread)
         for mode in ("f32", "f32s", "bf16"):
             try:
-                for _ in range(2):
+                for _ in range(5):
                     w = eng.forward(mel, dtype=mode)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
