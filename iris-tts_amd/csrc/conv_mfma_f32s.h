@@ -59,6 +59,8 @@ struct Launch {
     int out_off;
     int z_is_phase;       // the z part of blockIdx.x is the phase of problem 0; its weights start phase_bytes further per phase
     unsigned phase_bytes;
+    int ablate;           // diagnostics only (env IRIS_S3_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores, 8 no
+                          // residual loads.  Results are wrong.
     float* sum_y;         // set: last conv step of a stage -- a block runs ALL nz branches of its tile in the order
                           // 0, 1, .. (the reference's summation order, hifigan_pretrained.py:131-137) and stores only
                           // their mean here; the per-branch outputs are not written
@@ -85,7 +87,7 @@ __device__ __forceinline__ void stage_window(const Launch& a, const Problem& p, 
             const int r = idx / PPR, pc = idx - r * PPR;
             const int row = in_row0 + r;
             const bool ok = idx < total && row >= 0 && row < Lin;
-            v[u] = buf_load4(xr, ok ? (unsigned)(row * Cin + c0 + 4 * pc) * 4u : kOob, 0);
+            v[u] = buf_load4(xr, (ok && !(a.ablate & 1)) ? (unsigned)(row * Cin + c0 + 4 * pc) * 4u : kOob, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
             __builtin_amdgcn_sched_barrier(0);
         }
         load_a(ah[0], am[0], 0);
-        for (int n0 = 0; n0 < NG; n0 += D) {
+        for (int n0 = 0; n0 < ((a.ablate & 2) ? 0 : NG); n0 += D) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const int n = n0 + i;
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
     const unsigned tensor_bytes = (unsigned)a.L * (unsigned)a.C * 4u;
     const size_t ob = (size_t)b * a.L * a.C;
     const __amdgpu_buffer_rsrc_t yr = make_rsrc((ZS ? a.sum_y : p.y) + ob, tensor_bytes);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, p.res ? tensor_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.res ? p.res + ob : p.y, (p.res && !(a.ablate & 8)) ? tensor_bytes : 0u);
     unsigned pv[NP];
     int pscr[NP];
 #pragma unroll
@@ -290,7 +292,8 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
         __builtin_amdgcn_sched_barrier(0);
         if (!ZS || zi == n_pass - 1) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)pv[j], (int)msoff, 0);
+            for (int j = 0; j < NP; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pv[j]), (int)msoff, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         // store data stays live until every store of the group has issued (store-data note in mrf_conv_mfma_f32.h)
@@ -375,6 +378,8 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
     }
     const bool zs = a.sum_y != nullptr;
     a.sum_div = (float)nz;
+    static const int ablate_env = b16::env_int("IRIS_S3_ABLATE", 0);
+    a.ablate = ablate_env;
     // small grids (short utterances at batch 1): a launch lasts as long as its longest block, so the tile height is
     // halved when the grid has fewer than 2.5 blocks per CU (measured: 1.05 -> 0.88 ms at T = 100)
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
