@@ -1,14 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark of the HiFiGAN vocoder path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W] [--batch B --frames T]
+    python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path -- mel [B, 80, T] -> waveform [B, 256*T] through
 ``iris_hifigan_forward`` -- over one batch of synthetic mels that is already resident in HBM when
-the timed region starts.  N = 1 runs BASELINE.json configs[1] (batch 1, 80 x 1000 frames, fp32).
-For N > 1 every rank vocodes its own shard of the same size (weak scaling, no data-path collective
-but the final RCCL all-gather of the waveforms, which IS inside the step).
+the timed region starts.
+
+N = 1   BASELINE.json configs[1]: batch 1, 80 x 1000 frames, fp32 (the headline `value`).  Outside the
+        headline's timed region the same run also measures, as sub-records of the ONE JSON line:
+          grid            B = 1 x {100, 500, 1000} frames fp32 (north_star's reporting grid): ms, samples/s, RTF,
+                          MRF-kernel roofline fraction
+          host_inclusive  numpy in -> H2D -> forward -> D2H -> numpy out, what the reference's API does
+                          (src/iris/hifigan_pretrained.py:228,235); never `value`
+          configs2        BASELINE.json configs[2]: batch 32 x 500 frames, bf16 storage, HBM roofline of the MRF kernels
+          configs3_n1     the one-GPU leg of configs[3]: batch 256 x 1000 frames fp32 (so that 8-vs-1 is computable)
+          cpu_baseline    the oracle timed on the host cores; other_modes: the other arithmetic modes
+N > 1   BASELINE.json configs[3]: a GLOBAL batch of 256 mels x 1000 frames sharded over the N ranks (strong
+        scaling: total work fixed), one process per GPU, no data-path collective but the final RCCL all-gather
+        of the waveform shards, which IS inside the step; `grid` adds the same global batch at 100 and 500 frames.
+        When WORLD_SIZE is not set, ``python bench.py --gpus N`` starts the N ranks itself (torch.distributed.run
+        as a child process, before this process touches the GPU) and passes rank 0's line through.
 
 The JSON line also carries
   roofline      the dominant kernel (the MFMA Conv1d kernel behind the MRF ResBlocks): algorithmic
@@ -16,14 +29,17 @@ The JSON line also carries
                 on the stream the kernels run on; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
                 The path is a dense contraction at 118 FLOP/B: fp32 is MFMA-bound, not HBM-bound
                 (SURVEY.md 8d), so ``bound`` is "mfma"; the HBM fraction of the same launches is
-                reported beside it as ``hbm_frac``.
+                reported beside it as ``hbm_frac``.  ``traffic`` is NOT live: it is the committed PMC
+                measurement of the same workload (``traffic_source`` names the file).
   cpu_baseline  the oracle (torch fp32 restatement of the reference, oracle/hifigan_oracle.py) timed on
                 this box's host cores on a bounded sample of the same workload; rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -37,13 +53,65 @@ SAMPLE_RATE = 22050
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # dense, same table
 PEAK_HBM_GBS = 8000.0          # spec; 6.3 TB/s achievable
+GLOBAL_BATCH = 256             # BASELINE.json configs[3]
+MODE_TEXT = {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
+             "f32s": "fp32 storage, split-bf16 products in the ResBlock convs"}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="N = 1: mels per step (default 1: configs[1])")
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH,
+                    help="N > 1: mels per step over ALL ranks (default 256: configs[3]); rank r takes shard_bounds()[r]")
+    ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
+                    help="f32 = the parity path and the headline (default); bf16 = bf16 storage + bf16 MFMA "
+                         "(BASELINE.json configs[2] with --batch 32 --frames 500)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no grid / host_inclusive / "
+                    "configs2 / configs3_n1 / other_modes sub-records)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
+                    "roofline is then null; the default eager mode is the measured configuration)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collective "
+                    "path (barrier, all-gather, max-reduce) even with one rank: exercises the RCCL code path of N > 1 "
+                    "on a one-GPU box")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
+                    "gloo only for rehearsing the control flow on a box with fewer GPUs than ranks)")
+    ap.add_argument("--stub-engine", action="store_true", help="CONTROL-FLOW REHEARSAL ONLY (CPU tests of the launcher, the "
+                    "sharding and the gather): replaces the HIP engine by a stand-in that does not compute the vocoder; "
+                    "the line is marked \"stub\" and is not a measurement")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------
+# parent of an N > 1 run that was started as plain `python bench.py --gpus N`
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Starts one rank per GPU with torch.distributed.run and waits.  This process has made no HIP call (torch is
+    not even imported here): the ranks are children, nothing that touched the GPU is replaced by another program."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# ------------------------------------------------------------------------------------------------------
+# measurement helpers (rank processes)
+# ------------------------------------------------------------------------------------------------------
 def committed_traffic(batch, frames, dtype="f32"):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
+    """(HBM bytes per launch of the dominant kernel, source file) from the PMC passes committed under profiles/
     (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, gfx950 correction applied:
     profiles/r*_hbm_traffic.json, produced by tools/hbm_traffic.sh).  PMC counters cannot be collected from
-    inside this process, so the figure is the committed measurement of the same workload, or None when the
+    inside this process, so the figure is the committed measurement of the same workload, or (None, None) when the
     workload differs."""
     if (dtype, batch, frames) == ("f32", 1, 1000):
         files = [f for f in sorted((REPO / "profiles").glob("r*_hbm_traffic.json")) if "bf16" not in f.name]
@@ -52,11 +120,11 @@ def committed_traffic(batch, frames, dtype="f32"):
     else:
         files = []
     if not files:
-        return None
+        return None, None
     try:
-        return json.loads(files[-1].read_text())["mrf_traffic_bytes_per_launch"]
+        return json.loads(files[-1].read_text())["mrf_traffic_bytes_per_launch"], f"profiles/{files[-1].name} (committed PMC pass, not live)"
     except (KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(cfg, sd, mel, budget_s=20.0):
@@ -85,50 +153,115 @@ def cpu_baseline(cfg, sd, mel, budget_s=20.0):
             "rtf": best / (mel.shape[2] * 256 / SAMPLE_RATE) if mel.shape[0] == 1 else None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="mels per GPU (default: configs[1], batch 1)")
-    ap.add_argument("--frames", type=int, default=1000, help="mel frames per item")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "f32s"], default="f32",
-                    help="f32 = the parity path and the headline (default); bf16 = bf16 storage + bf16 MFMA "
-                         "(BASELINE.json configs[2] with --batch 32 --frames 500)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
-    ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
-                    "roofline is then null; the default eager mode is the measured configuration)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collective "
-                    "path (barrier, all-gather, max-reduce) even with one rank: exercises the RCCL code path of N > 1 "
-                    "on a one-GPU box")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
-                    "gloo only for rehearsing the control flow on a box with fewer GPUs than ranks)")
-    args = ap.parse_args()
+def summarize_records(recs, steps, cfg):
+    """Per-kind and per-MRF-stage sums of the live HIP-event records of `steps` forwards."""
+    by_kind, detail = {}, {}
+    for r in recs:
+        k = by_kind.setdefault(r["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+        k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += 1
+    for kind, k in by_kind.items():
+        detail[kind] = {"launches_per_step": k["n"] // steps, "ms_per_step": k["ms"] / steps,
+                        "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12, "gbs": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
+    for stage in range(cfg.num_upsamples):
+        rs = [r for r in recs if r["kind"] == "mrf_resblock_conv" and r["stage"] == stage]
+        ms = sum(r["ms"] for r in rs)
+        if ms > 0:
+            detail[f"mrf_stage{stage}_C{cfg.stage_channels(stage)}"] = {
+                "ms_per_step": ms / steps, "tflops": sum(r["flops"] for r in rs) / (ms * 1e-3) / 1e12,
+                "gbs": sum(r["bytes"] for r in rs) / (ms * 1e-3) / 1e9}
+    return by_kind, detail
 
+
+def roofline_of(by_kind, dtype, steps, ms_per_step, batch, frames):
+    """The `roofline` object of the dominant kernel (the MRF ResBlock conv launches) from live records."""
+    dom = by_kind.get("mrf_resblock_conv")
+    if not dom or dom["ms"] <= 0:
+        return None
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    traffic, source = committed_traffic(batch, frames, "bf16" if dtype == "bf16" else "f32") if dtype != "f32s" else (None, None)
+    common = {"traffic": traffic, "traffic_source": source, "launches_per_step": dom["n"] // steps,
+              "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
+              "bytes_per_launch": dom["bytes"] / dom["n"], "share_of_step": dom["ms"] / steps / ms_per_step}
+    if dtype in ("f32", "f32s"):
+        # f32s: three bf16 MFMAs per fp32 product -> the matrix roof for fp32-equivalent FLOP is a third of the bf16 peak
+        peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+        return {"kernel": ("mrf_conv_mfma_f32_kernel" if dtype == "f32" else "conv_mfma_f32s_kernel (split-bf16 products)")
+                          + " (MRF ResBlock Conv1d steps)",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS, **common}
+    # bf16: the MRF launches taken together need more HBM time (bytes / 8 TB/s) than MFMA time
+    # (FLOP / 2.5 PFLOP/s) -- 235 FLOP/B against a machine balance of 312 -- so HBM is the binding roof
+    return {"kernel": "bf16 MRF ResBlock kernels (mrf_pair_bf16_kernel / conv_mfma_bf16_kernel)",
+            "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+            "mfma_achieved_tflops": achieved, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+            "mfma_frac": achieved / PEAK_BF16_MFMA_TFLOPS, **common}
+
+
+class StubEngine:
+    """--stub-engine: stands in for GeneratorEngine so that the launcher, the sharding, the gather and the JSON
+    contract can be rehearsed on CPU (gloo).  It does NOT compute the vocoder (every output sample is the mean of
+    its frame's mel bins); nothing measured with it is a result."""
+    hop_length = 256
+
+    def forward(self, mel, out=None, dtype=None):
+        wav = mel.mean(dim=1).repeat_interleave(self.hop_length, dim=1)
+        if out is not None:
+            out.copy_(wav)
+            return out
+        return wav
+
+    def set_profiling(self, enabled):
+        pass
+
+    def read_profile(self):
+        return []
+
+
+def timed_forward(eng, mel, dtype, steps, warmup, dev, profile, cfg):
+    """One single-GPU measurement outside the headline: ms per step (+ live per-launch records when profiling)."""
+    import torch
+    wav = torch.empty((mel.shape[0], mel.shape[2] * eng.hop_length), dtype=torch.float32, device=dev)
+    for _ in range(warmup):
+        eng.forward(mel, out=wav, dtype=dtype)
+    torch.cuda.synchronize(dev)
+    eng.set_profiling(profile)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward(mel, out=wav, dtype=dtype)
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    recs = eng.read_profile() if profile else []
+    eng.set_profiling(False)
+    return ms, recs, wav
+
+
+def rank_main(args):
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from iris._engine import GeneratorEngine, algorithmic_work
     from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
-    from iris.distributed import gather_waveforms
+    from iris.distributed import gather_waveforms, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the vocoder path has no CPU fallback)")
-    n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev and args.backend == "nccl":
-        raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} HIP device(s): RCCL needs one GPU per rank")
-    dev = torch.device("cuda", local_rank % n_dev)     # (ranks share a GPU only in a gloo rehearsal)
-    torch.cuda.set_device(dev)
+    stub = args.stub_engine
+    if stub:
+        dev = torch.device("cpu")
+        if args.backend == "nccl" and (world > 1 or args.force_dist):
+            raise SystemExit("--stub-engine rehearses on CPU: use --backend gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (the vocoder path has no CPU fallback)")
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev and args.backend == "nccl":
+            raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} HIP device(s): RCCL needs one GPU per rank")
+        dev = torch.device("cuda", local_rank % n_dev)     # (ranks share a GPU only in a gloo rehearsal)
+        torch.cuda.set_device(dev)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -140,148 +273,208 @@ def main():
 
     cfg = GeneratorConfig()
     sd = seeded_state_dict(cfg, seed=2024)                       # random-init weights of the V1 architecture
-    B, T = args.batch, args.frames
-    mel_np = seeded_mel(1002 + rank, B, T)                       # SURVEY.md 8d seeds
-    eng = GeneratorEngine(cfg, sd, dev)
-    mel = torch.from_numpy(mel_np).to(dev)
-    wav = torch.empty((B, T * eng.hop_length), dtype=torch.float32, device=dev)
-    gathered = torch.empty((B * world, T * eng.hop_length), dtype=torch.float32, device=dev) if use_dist else None
+    T = args.frames
+    strong = world > 1
+    if strong:
+        G = args.global_batch                                    # configs[3]: the global batch is fixed, ranks split it
+        lo, hi = shard_range(G, rank, world)
+        B = hi - lo
+        seed = 1004 + rank                                       # SURVEY.md 8d seeds
+    else:
+        B = args.batch if args.batch is not None else 1
+        G = B
+        seed = 1002
+    if stub:
+        eng = StubEngine()
+    else:
+        from iris._engine import GeneratorEngine, algorithmic_work
+        eng = GeneratorEngine(cfg, sd, dev)
+    hop = eng.hop_length
 
-    def step():
-        if args.graph:
-            out = eng.forward_graph(mel, dtype=args.dtype)
-        else:
-            out = eng.forward(mel, out=wav, dtype=args.dtype)
-        if use_dist:
-            gather_waveforms(out, B * world, out=gathered)
+    def sync():
+        if not stub:
+            torch.cuda.synchronize(dev)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
-    for _ in range(args.warmup):
-        step()
-    profile = not args.no_profile and not args.graph
-    fence()
-    eng.set_profiling(profile)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    recs = eng.read_profile() if profile else []
-    eng.set_profiling(False)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_sharded(frames, steps, warmup, profile):
+        """`steps` timed steps of this rank's shard at `frames` frames (+ the gather); max over ranks."""
+        mel_np = seeded_mel(seed, max(B, 1), frames)[:B]
+        mel = torch.from_numpy(mel_np).to(dev)
+        wav = torch.empty((B, frames * hop), dtype=torch.float32, device=dev)
+        gathered = torch.empty((G, frames * hop), dtype=torch.float32, device=dev) if use_dist else None
 
-    samples_per_step = world * B * T * eng.hop_length
+        def step():
+            if args.graph and not stub:
+                out = eng.forward_graph(mel, dtype=args.dtype)
+            else:
+                out = eng.forward(mel, out=wav, dtype=args.dtype)
+            if use_dist:
+                gather_waveforms(out, G, out=gathered)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        eng.set_profiling(profile)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        recs = eng.read_profile() if profile else []
+        eng.set_profiling(False)
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, recs, mel_np, mel
+
+    # ---- the headline: W untimed warm-up steps, exactly K timed steps between barrier + synchronize -------------
+    profile = not args.no_profile and not args.graph and not stub
+    elapsed, recs, mel_np, mel = run_sharded(T, args.steps, args.warmup, profile)
+    samples_per_step = G * T * hop
     value = samples_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+    by_kind, detail = summarize_records(recs, args.steps, cfg) if recs else ({}, {})
+    roofline = roofline_of(by_kind, args.dtype, args.steps, ms_per_step, B, T) if recs else None
 
-    # ---- roofline of the dominant kernel, from the live HIP-event records -----------------------
-    roofline = None
-    detail = {}
-    if recs:
-        by_kind = {}
-        for r in recs:
-            k = by_kind.setdefault(r["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-            k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += 1
-        for kind, k in by_kind.items():
-            detail[kind] = {"launches_per_step": k["n"] // args.steps, "ms_per_step": k["ms"] / args.steps,
-                            "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12, "gbs": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
-        for stage in range(cfg.num_upsamples):
-            rs = [r for r in recs if r["kind"] == "mrf_resblock_conv" and r["stage"] == stage]
-            ms = sum(r["ms"] for r in rs)
-            detail[f"mrf_stage{stage}_C{cfg.stage_channels(stage)}"] = {
-                "ms_per_step": ms / args.steps, "tflops": sum(r["flops"] for r in rs) / (ms * 1e-3) / 1e12,
-                "gbs": sum(r["bytes"] for r in rs) / (ms * 1e-3) / 1e9}
-        dom = by_kind["mrf_resblock_conv"]
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        if args.dtype in ("f32", "f32s"):
-            # f32s: three bf16 MFMAs per fp32 product -> the matrix roof for fp32-equivalent FLOP is a third of the bf16 peak
-            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
-            roofline = {"kernel": ("mrf_conv_mfma_f32_kernel" if args.dtype == "f32" else "conv_mfma_f32s_kernel (split-bf16 products)")
-                                  + " (MRF ResBlock Conv1d steps, 24 launches/forward)",
-                        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": committed_traffic(B, T) if args.dtype == "f32" else None,
-                        "avg_launch_ms": dom["ms"] / dom["n"], "flop_per_launch": dom["flops"] / dom["n"],
-                        "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS,
-                        "bytes_per_launch": dom["bytes"] / dom["n"],
-                        "share_of_step": dom["ms"] / args.steps / ms_per_step}
-        else:
-            # bf16: the MRF launches taken together need more HBM time (bytes / 8 TB/s) than MFMA time
-            # (FLOP / 2.5 PFLOP/s) -- 235 FLOP/B against a machine balance of 312 -- so HBM is the binding roof
-            roofline = {"kernel": "conv_mfma_bf16_kernel (MRF ResBlock Conv1d steps, 24 launches/forward)",
-                        "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": gbs / PEAK_HBM_GBS, "traffic": committed_traffic(B, T, "bf16"),
-                        "avg_launch_ms": dom["ms"] / dom["n"], "bytes_per_launch": dom["bytes"] / dom["n"],
-                        "flop_per_launch": dom["flops"] / dom["n"],
-                        "mfma_achieved_tflops": achieved, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
-                        "mfma_frac": achieved / PEAK_BF16_MFMA_TFLOPS,
-                        "share_of_step": dom["ms"] / args.steps / ms_per_step}
+    # ---- N > 1: the rest of the reporting grid (same global batch, 100 and 500 frames); every rank takes part --------
+    grid = []
+    if strong and not args.no_extras:
+        for frames in (100, 500, 1000):
+            if frames == T:
+                grid.append({"frames": T, "global_batch": G, "ms_per_step": ms_per_step, "samples_per_s": value})
+                continue
+            e, _, _, _ = run_sharded(frames, max(3, args.steps // 2), 1, False)
+            n = max(3, args.steps // 2)
+            grid.append({"frames": frames, "global_batch": G, "ms_per_step": 1e3 * e / n, "samples_per_s": G * frames * hop * n / e})
 
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
-    work = algorithmic_work(cfg)
+    flop_per_frame = 614_105_088 if stub else algorithmic_work(cfg)["flop_per_frame"]
+    if strong:
+        workload = (f"HiFiGAN-V1 generator, global batch {G} x 80-mel x {T} frames sharded over {world} GPUs "
+                    f"({B} items on rank 0) -> {T * hop} samples each, {MODE_TEXT[args.dtype]}"
+                    + (" (BASELINE.json configs[3])" if (G, args.dtype) == (GLOBAL_BATCH, "f32") else ""))
+    else:
+        workload = (f"HiFiGAN-V1 generator, batch {B} x 80-mel x {T} frames -> {T * hop} samples each, {MODE_TEXT[args.dtype]}"
+                    + (" (BASELINE.json configs[1])" if (B, T, args.dtype) == (1, 1000, "f32") else "")
+                    + (" (BASELINE.json configs[2])" if (B, T, args.dtype) == (32, 500, "bf16") else ""))
     out = {
         "metric": "audio samples/sec (22.05 kHz) on 80-mel x %d-frame batch" % T,
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"HiFiGAN-V1 generator, batch {B} per GPU x 80-mel x {T} frames -> {T * eng.hop_length} samples "
-                               f"each, " + {"f32": "fp32", "bf16": "bf16 storage / fp32 accumulate",
-                                            "f32s": "fp32 storage, split-bf16 products in the ResBlock convs"}[args.dtype]
-                               + (" (BASELINE.json configs[1])" if (B, T, args.dtype) == (1, 1000, "f32") else "")
-                               + (" (BASELINE.json configs[2])" if (B, T, args.dtype) == (32, 500, "bf16") else ""),
-                   "batch_per_gpu": B, "global_batch": B * world, "frames": T, "hop_length": eng.hop_length,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": args.dtype,
+        "data": "stub engine: control-flow rehearsal, NOT a measurement" if stub else "synthetic",
+        "config": {"workload": workload, "batch_per_gpu": B, "global_batch": G, "frames": T, "hop_length": hop,
                    "weights": "random-init (seeded) V1 architecture, 13,926,017 values",
-                   "sharding": (f"batch items across ranks, all-gather of waveforms over {args.backend}"
+                   "sharding": (f"contiguous balanced shards of the global batch, one process per GPU, all-gather of the "
+                                f"waveform shards over {args.backend}"
                                 + (" (RCCL)" if args.backend == "nccl" else " (control-flow rehearsal, not a measurement)"))
                                if world > 1 else "single GPU",
                    "launch_events_in_timed_region": profile, "hipgraph_replay": bool(args.graph)},
-        "rtf": (ms_per_step * 1e-3) / (T * eng.hop_length / SAMPLE_RATE) if B == 1 else None,
-        "flop_per_step": work["flop_per_frame"] * B * T * world,
-        "tflops_whole_path": work["flop_per_frame"] * B * T * world / (ms_per_step * 1e-3) / 1e12,
+        "rtf": (ms_per_step * 1e-3) / (T * hop / SAMPLE_RATE) if G == 1 else None,
+        "flop_per_step": flop_per_frame * G * T,
+        "tflops_whole_path": flop_per_frame * G * T / (ms_per_step * 1e-3) / 1e12,
         "roofline": roofline, "kernels": detail,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if stub:
+        out["stub"] = True
+    if grid:
+        out["grid"] = grid
+
+    extras = world == 1 and not stub and not args.no_extras and not args.force_dist
+    if extras:
+        # ---- north_star's reporting grid at batch 1 (outside the headline's timed region) ------------------------------
+        g = []
+        for frames in (100, 500, 1000):
+            m = torch.from_numpy(seeded_mel(1001 if frames == 100 else 1002, 1, frames)).to(dev)
+            ms, r, _ = timed_forward(eng, m, "f32", 20, 5, dev, True, cfg)
+            bk, _ = summarize_records(r, 20, cfg)
+            rf = roofline_of(bk, "f32", 20, ms, 1, frames)
+            g.append({"frames": frames, "batch": 1, "dtype": "f32", "ms": ms, "samples_per_s": frames * hop / (ms * 1e-3),
+                      "rtf": (ms * 1e-3) / (frames * hop / SAMPLE_RATE),
+                      "roofline_frac": rf["frac"] if rf else None, "mrf_tflops": rf["achieved"] if rf else None})
+        out["grid"] = g
+        # ---- host-inclusive: numpy in -> numpy out, PCIe both ways, synchronous (never `value`) --------------------------
+        def host_call(x):
+            t = torch.from_numpy(x).float().to(dev)                      # hifigan_pretrained.py:228
+            return eng.forward(t, dtype="f32").cpu().numpy()            # :231-235
+        for _ in range(3):
+            host_call(mel_np)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            host_call(mel_np)
+        hi_ms = 1e3 * (time.perf_counter() - t0) / 10
+        out["host_inclusive"] = {"ms": hi_ms, "samples_per_s": B * T * hop / (hi_ms * 1e-3), "batch": B, "frames": T,
+                                 "note": "numpy mel -> H2D -> forward -> D2H -> numpy waveform per call (what the reference's "
+                                         "API does, hifigan_pretrained.py:228,235); never `value`"}
+        # ---- BASELINE.json configs[2]: batch 32 x 500 frames, bf16 storage ------------------------------------------------
+        try:
+            m2 = torch.from_numpy(seeded_mel(1003, 32, 500)).to(dev)
+            ms2, r2, _ = timed_forward(eng, m2, "bf16", 10, 3, dev, True, cfg)
+            bk2, det2 = summarize_records(r2, 10, cfg)
+            out["configs2"] = {"workload": "batch 32 x 80-mel x 500 frames, bf16 storage / fp32 accumulate (BASELINE.json configs[2])",
+                               "dtype": "bf16", "ms_per_step": ms2, "samples_per_s": 32 * 500 * hop / (ms2 * 1e-3), "steps": 10,
+                               "roofline": roofline_of(bk2, "bf16", 10, ms2, 32, 500), "kernels": det2}
+            del m2
+        except Exception as exc:
+            out["configs2"] = {"error": str(exc)}
+        # ---- the one-GPU leg of configs[3]: batch 256 x 1000 frames fp32 (58 GB of workspace) -----------------------------
+        try:
+            m3 = torch.from_numpy(seeded_mel(1004, GLOBAL_BATCH, 1000)).to(dev)
+            ms3, _, _ = timed_forward(eng, m3, "f32", 3, 1, dev, False, cfg)
+            out["configs3_n1"] = {"workload": f"global batch {GLOBAL_BATCH} x 80-mel x 1000 frames on ONE GPU, fp32 (the N = 1 leg of "
+                                              "BASELINE.json configs[3])", "dtype": "f32", "ms_per_step": ms3, "steps": 3,
+                                  "samples_per_s": GLOBAL_BATCH * 1000 * hop / (ms3 * 1e-3),
+                                  "tflops_whole_path": flop_per_frame * GLOBAL_BATCH * 1000 / (ms3 * 1e-3) / 1e12}
+            del m3
+        except Exception as exc:
+            out["configs3_n1"] = {"error": str(exc)}
+        eng.release_workspace()                                           # the 58 GB, before the CPU leg
+        torch.cuda.empty_cache()
+
+    if world == 1 and not stub and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, mel_np)
-        # Beside the headline (outside its timed region): the same workload in the other arithmetic modes of the
-        # library, each with its max-abs distance to the CPU checker's waveform.  `value` above is always --dtype.
-        ref = cpu_baseline.last_output
-        modes = []
-        time.sleep(1.0)                     # let the CPU leg's worker threads go idle (they slow the launching thread)
-        for mode in ("f32", "f32s", "bf16"):
-            try:
-                for _ in range(5):
-                    w = eng.forward(mel, dtype=mode)
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    w = eng.forward(mel, dtype=mode)
-                torch.cuda.synchronize(dev)
-                dt = (time.perf_counter() - t0) / 10
-                modes.append({"dtype": mode, "ms_per_step": 1e3 * dt, "value": B * T * eng.hop_length / dt, "unit": "samples/s",
-                              "max_abs_err_vs_cpu_checker": float(np.abs(w.cpu().numpy() - ref).max()),
-                              "note": {"f32": "exact fp32 MFMA (the parity path; no launch events here)",
-                                       "f32s": "fp32 storage/accumulate, split-bf16 products in the ResBlock convs (opt-in)",
-                                       "bf16": "bf16 storage, fp32 accumulate (opt-in; tolerance unpinned by the reference)"}[mode]})
-            except Exception as exc:      # a mode the configuration does not support
-                modes.append({"dtype": mode, "error": str(exc)})
-        out["other_modes"] = modes
+        if extras:
+            # Beside the headline (outside its timed region): the same workload in the other arithmetic modes of the
+            # library, each with its max-abs distance to the CPU checker's waveform.  `value` above is always --dtype.
+            ref = cpu_baseline.last_output
+            modes = []
+            time.sleep(1.0)                     # let the CPU leg's worker threads go idle (they slow the launching thread)
+            for mode in ("f32", "f32s", "bf16"):
+                try:
+                    ms, _, w = timed_forward(eng, mel, mode, 10, 5, dev, False, cfg)
+                    modes.append({"dtype": mode, "ms_per_step": ms, "value": B * T * hop / (ms * 1e-3), "unit": "samples/s",
+                                  "max_abs_err_vs_cpu_checker": float(np.abs(w.cpu().numpy() - ref).max()),
+                                  "note": {"f32": "exact fp32 MFMA (the parity path; no launch events here)",
+                                           "f32s": "fp32 storage/accumulate, split-bf16 products in the ResBlock convs (opt-in)",
+                                           "bf16": "bf16 storage, fp32 accumulate (opt-in; tolerance unpinned by the reference)"}[mode]})
+                except Exception as exc:      # a mode the configuration does not support
+                    modes.append({"dtype": mode, "error": str(exc)})
+            out["other_modes"] = modes
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))           # no GPU call has happened in this process
+    rank_main(args)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,14 @@
  *     asynchronous on it and performs no allocation and no synchronisation;
  *   - every function returns an iris_hifigan_status; on failure the calling thread's
  *     message is available from iris_hifigan_last_error(); no exception crosses the ABI;
- *   - a handle may be used by one thread at a time.
+ *   - a handle may be used by one thread at a time, with ONE forward in flight: a handle owns per-forward
+ *     device state (the next-tile counters of the persistent MRF kernel, the profiling events) and every
+ *     forward of a handle writes the same caller-provided workspace, so a second forward of the same handle
+ *     (another stream, or a hipGraph replay that captured it) must be ordered after the first one -- put them
+ *     on one stream or give each stream its own handle and workspace;
+ *   - a handle belongs to the HIP device that was current in iris_hifigan_create; forward selects that device
+ *     for its launches and restores the caller's, so `stream` and all *_dev pointers must belong to it;
+ *   - the library reads no environment variable (diagnostic switches exist only in the `make diag` build).
  *
  * Activations inside the library are channels-last [B, L, C], fp32 (bf16 with dtype
  * IRIS_HIFIGAN_BF16); the mel comes in as the
@@ -34,7 +41,7 @@
 extern "C" {
 #endif
 
-#define IRIS_HIFIGAN_ABI_VERSION 1
+#define IRIS_HIFIGAN_ABI_VERSION 2
 #define IRIS_HIFIGAN_MAX_STAGES 8    /* upsample stages            */
 #define IRIS_HIFIGAN_MAX_KERNELS 8   /* MRF branches per stage     */
 #define IRIS_HIFIGAN_MAX_DILATIONS 8 /* conv pairs per ResBlock    */
@@ -120,6 +127,29 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                              void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
                              int32_t dtype, void* stream);
 
+/* ---- intermediates (parity tests of the layers inside a forward; not needed by a caller) ----
+ * forward_until queues the same launches as forward up to and including MRF step `stop_step`
+ * (0 .. 2*num_dilations-1: even = convs1[m], odd = convs2[m] + residual, hifigan_pretrained.py:64-71) of
+ * upsample stage `stop_stage` and returns; no waveform is produced.  The intermediates are then in the
+ * workspace at the offsets workspace_layout reports, channels-last [B, L_stage, C_stage]:
+ *   pre  conv_pre output [B, T, C0];  up  the stage's ConvTranspose1d output;
+ *   y[j] running x of ResBlock j (after an odd step);  xt[j] output of convs1 of ResBlock j (after an even step).
+ * *mean_in_y0 (may be NULL) is set to 1 when stop_step is the last step of the stage and the kernel already
+ * stored (y[0]+y[1]+y[2])/num_kernels (hifigan_pretrained.py:131-137) in y[0] instead of the branch outputs. */
+typedef struct iris_hifigan_workspace_map {
+    uint64_t pre_offset, up_offset;                 /* byte offsets into the workspace */
+    uint64_t y_offset[IRIS_HIFIGAN_MAX_KERNELS];
+    uint64_t xt_offset[IRIS_HIFIGAN_MAX_KERNELS];
+    uint64_t total_bytes;                           /* == iris_hifigan_workspace_bytes */
+    int32_t element_bytes;                          /* 4 (fp32 storage) or 2 (bf16 storage) */
+    int32_t reserved;
+} iris_hifigan_workspace_map;
+int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, int32_t T, int32_t dtype,
+                                      iris_hifigan_workspace_map* out);
+int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                                   void* workspace_dev, uint64_t workspace_bytes, int32_t dtype,
+                                   int32_t stop_stage, int32_t stop_step, int32_t* mean_in_y0, void* stream);
+
 /* Samples of waveform per mel frame (256 for the V1 config). */
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
 
@@ -148,6 +178,19 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
                                   const float* w_host, const float* bias_host, float* y_dev,
                                   int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
                                   void* stream);
+
+/* One grouped MRF step of the fp32 path -- the hot kernel -- on its own: the three ResBlock branches
+ * (kernel sizes k[j] = 3, 7, 11; hifigan_pretrained.py:64-71,130-136) each run
+ *     y_j = Conv1d_{k[j], dil[j]}(LeakyReLU(x_j)) (+ res_j)
+ * on fp32 channels-last tensors [B, L, C].  mean_dev != NULL makes it the last step of a stage: only
+ * ((y_0 + y_1) + y_2) / 3 is stored, into mean_dev (y_dev is then unused).
+ * plan: 0 = the library's own choice, 1 = persistent blocks with full-height tiles, 2 = with half-height tiles,
+ * 3 = one branch per block (the small-problem mode; with mean_dev the last-arriving branch block of a tile
+ * forms the mean).  Returns IRIS_HIFIGAN_UNSUPPORTED when the shape cannot take the MRF kernel. */
+int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* w_host, const float* const* bias_host,
+                                 const float* const* res_dev, float* const* y_dev, float* mean_dev,
+                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, int32_t plan, void* stream);
 
 /* bf16 variants of the two layers above (dtype IRIS_HIFIGAN_BF16): x_dev / res_dev / y_dev are bf16
  * channels-last [B, L, C] (C_in % 8 == 0, C_out % 4 == 0); host weights are fp32 in the reference layout and are

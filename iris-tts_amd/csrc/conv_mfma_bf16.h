@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "diag_env.h"
 
 namespace iris {
 namespace b16 {
@@ -537,10 +538,8 @@ inline void pack_convt_bf16(const float* w, int C_in, int C_out, int k, int u, u
 // ---- launch ----------------------------------------------------------------------------------------
 struct Tile { int WT, WC, MT, NT, CIC, MINB, T_BLK, CO_BLK; };
 
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
 inline Tile pick_tile(int C_in, int C_out) {
-    static const int v32 = env_int("IRIS_B16_TILE32", 0), v64 = env_int("IRIS_B16_TILE64", 0), v128 = env_int("IRIS_B16_TILE128", 0);
+    const int v32 = IRIS_DIAG_ENV("IRIS_B16_TILE32", 0), v64 = IRIS_DIAG_ENV("IRIS_B16_TILE64", 0), v128 = IRIS_DIAG_ENV("IRIS_B16_TILE128", 0);
     Tile t;
     if (C_out <= 32) {
         t.WT = 4; t.WC = 1; t.NT = 1;
@@ -575,8 +574,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     a.n_ct = packed_cotiles(a.C_out);
     a.nz = nz;
     a.inv_n_mrf = a.n_mrf > 0 ? 1.0f / (float)a.n_mrf : 1.0f;
-    static const int ablate_env = env_int("IRIS_B16_ABLATE", 0);
-    a.ablate = ablate_env;
+    a.ablate = IRIS_DIAG_ENV("IRIS_B16_ABLATE", 0);
     int span = 0;
     const int np = a.z_is_phase ? 1 : nz;
     if (np > kMaxGroup) return hipErrorInvalidValue;
@@ -596,7 +594,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     const int n_t = (a.n_idx + t.T_BLK - 1) / t.T_BLK;
     a.n_items = a.z_is_phase ? n_t : n_t * nz;
     a.n_share = a.z_is_phase ? a.n_co_blk * nz : a.n_co_blk;
-    static const int xcd_env = env_int("IRIS_B16_XCDGROUP", 1);
+    const int xcd_env = IRIS_DIAG_ENV("IRIS_B16_XCDGROUP", 1);
     a.xcd_group = xcd_env && a.n_share > 1 && a.n_items >= 64;      // (a few items would leave XCDs without work)
     const int gx = a.xcd_group ? ((a.n_items + 7) / 8) * 8 * a.n_share : a.n_items * a.n_share;
     dim3 grid((unsigned)gx, (unsigned)a.B, 1u), block(256);

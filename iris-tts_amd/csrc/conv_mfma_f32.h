@@ -32,6 +32,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include "diag_env.h"
 
 namespace iris {
 
@@ -426,6 +428,23 @@ inline ConvTile pick_tile(int C_in, int C_out) {
     return t;
 }
 
+// Compute units of the CURRENT HIP device (launch plans are sized per device: a process may hold engines on
+// several GPUs, so the count is cached per device ordinal, not per process).
+inline int device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const int slot = dev < 64 ? dev : 63;
+    int n = dev < 64 ? cache[slot].load(std::memory_order_relaxed) : 0;
+    if (n <= 0) {
+        n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n <= 0) n = 256;
+        if (dev < 64) cache[slot].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // Fills the derived fields of `a` (n_co_blk, Gp, n_ct) and launches. `nz` = problems or phases.
 inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
@@ -438,23 +457,21 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
         const int s = (a.p[j].ks - 1) * a.p[j].dil;
         if (s > span) span = s;
     }
-    static const int serial_env = [] { const char* e = getenv("IRIS_HIFIGAN_ZSERIAL"); return e ? atoi(e) : 1; }();
+    const int serial_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_ZSERIAL", 1);
     a.z_serial = (!a.z_is_phase && nz > 1 && serial_env) ? serial_env : 0;
     a.nz_serial = nz;
     if (a.z_serial) nz = 1;
     a.nz = nz;
     // Small grids (conv_pre, the first upsamplers, short utterances): a launch costs one tile's serial
     // time, so when the grid cannot give every CU two blocks the tile height is halved (MT = 1).
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
-                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static const int mt_env = [] { const char* e = getenv("IRIS_HIFIGAN_CONV_MT"); return e ? atoi(e) : 0; }();
+    const int n_cu = device_cu_count();
+    const int mt_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_CONV_MT", 0);
     const long long blocks2 = (long long)((a.n_idx + t.T_BLK - 1) / t.T_BLK) * a.n_co_blk * nz * a.B;
     const int MT = mt_env ? mt_env : (blocks2 < 2LL * n_cu ? 1 : 2);
     const int T_BLK = t.WT * MT * 32;
     const size_t lds_bytes = (size_t)(T_BLK + span) * (t.CIC + 4) * sizeof(float);
     const int n_t = (a.n_idx + T_BLK - 1) / T_BLK;
-    static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = ablate_env;
+    a.ablate = IRIS_DIAG_ENV("IRIS_HIFIGAN_ABLATE", 0);
     dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
 #define IRIS_LAUNCH_K(...)                                                                        \

@@ -378,13 +378,13 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
     }
     const bool zs = a.sum_y != nullptr;
     a.sum_div = (float)nz;
-    static const int ablate_env = b16::env_int("IRIS_S3_ABLATE", 0);
+    const int ablate_env = IRIS_DIAG_ENV("IRIS_S3_ABLATE", 0);
     a.ablate = ablate_env;
     // small grids (short utterances at batch 1): a launch lasts as long as its longest block, so the tile height is
     // halved when the grid has fewer than 2.5 blocks per CU (measured: 1.05 -> 0.88 ms at T = 100)
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
                                  (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    static const int mt_env = b16::env_int("IRIS_S3_MT", 0);
+    const int mt_env = IRIS_DIAG_ENV("IRIS_S3_MT", 0);
     const long long blocks2 = (long long)((n_rows + t.T_BLK - 1) / t.T_BLK) * (zs ? 1 : nz) * a.n_co_blk * a.B;
     if (mt_env ? mt_env == 1 : 2 * blocks2 < 5LL * n_cu) { t.MT = 1; t.T_BLK = t.WT * 32; }
     const int SB = t.CIC * 2 + 16;

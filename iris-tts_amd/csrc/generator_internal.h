@@ -10,8 +10,32 @@
 #include <vector>
 
 #include "../../include/iris_hifigan.h"
+#include "diag_env.h"
 
 namespace iris {
+
+constexpr int kTileCounterWords = 256;   // per-launch next-tile counters of one forward (MRF kernel, large batches)
+
+// forward_until: stop after MRF step `step` of stage `stage` has been queued (stage < 0: run the whole forward)
+struct ForwardStop { int stage; int step; };
+
+// Runs the rest of the scope under the handle's device and restores the caller's (a process may hold generators on
+// several GPUs; launches, events and the CU-count-based launch plans must all refer to the handle's device).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // records the message for iris_hifigan_last_error() and returns `code`
 int fail(int code, const char* fmt, ...);
@@ -128,8 +152,10 @@ struct Prof {
 // ---- bf16-storage path (iris_hifigan_bf16.hip) ----
 int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob16
 uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T);
+int bf16_workspace_map(const iris_hifigan_handle* h, int B, int T, iris_hifigan_workspace_map* out);
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
-                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream);
+                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream, const ForwardStop& stop,
+                 int32_t* mean_in_y0);
 
 // ---- fp32 storage with split-bf16 products for the ResBlock convs (conv_mfma_f32s.h; iris_hifigan_bf16.hip) ----
 int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob_s3 (null if unsupported)

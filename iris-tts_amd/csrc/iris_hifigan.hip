@@ -212,22 +212,21 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
         memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
         src += l.C_out;
     });
+    // the generator lives on the device that is current now; every later call runs under that device
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess) e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (h->blob) (void)hipFree(h->blob);
-        delete h;
+        (void)iris_hifigan_destroy(h);          // frees whatever was allocated so far
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "weight upload failed: %s", hipGetErrorString(e));
     }
-    if (hipMalloc(&h->tile_counters, 256 * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
+    if (hipMalloc(&h->tile_counters, kTileCounterWords * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
     int rc16 = bf16_build_blob(h, weights_host);
     if (rc16 == IRIS_HIFIGAN_OK) rc16 = f32s_build_blob(h, weights_host);
     if (rc16 != IRIS_HIFIGAN_OK) {
-        (void)hipFree(h->blob);
-        delete h;
+        (void)iris_hifigan_destroy(h);
         return rc16;
     }
     *out = h;
@@ -283,27 +282,35 @@ int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_re
     return IRIS_HIFIGAN_OK;
 }
 
-int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
-                             void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
-                             int32_t dtype, void* stream_) {
+}  // extern "C"
+
+namespace {
+
+// Checks shared by forward and forward_until.
+int check_forward_args(const iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T, const void* workspace_dev,
+                       int32_t dtype) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16 && dtype != IRIS_HIFIGAN_F32_SPLIT)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
-    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
-    if (!mel_dev || !wav_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
+    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;
+    if (!mel_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
     if (B > 65535) return fail(IRIS_HIFIGAN_UNSUPPORTED, "batch %d exceeds 65535 (grid.y)", B);
     if ((int64_t)T * h->hop > (int64_t)1 << 30)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "T*hop = %lld exceeds 2^30 rows", (long long)T * h->hop);
-    if (dtype == IRIS_HIFIGAN_BF16)
-        return bf16_forward(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, (hipStream_t)stream_);
+    return IRIS_HIFIGAN_OK;
+}
+
+// The fp32 / split-product forward.  `stop` (forward_until only): return after MRF step stop.step of stage
+// stop.stage has been queued; *mean_in_y0 then says where that stage's result lies (forward_until's contract).
+int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T, void* wav_dev, void* workspace_dev,
+                uint64_t workspace_bytes, int32_t dtype, hipStream_t stream, const ForwardStop& stop, int32_t* mean_in_y0) {
     const WsLayout w = ws_layout(h, B, T);
     if (workspace_bytes < w.total * sizeof(float))
         return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
                     (unsigned long long)workspace_bytes, (unsigned long long)(w.total * sizeof(float)));
-    hipStream_t stream = (hipStream_t)stream_;
     float* ws = (float*)workspace_dev;
     const float* blob = h->blob;
     const float slope = h->cfg.lrelu_slope;
@@ -313,8 +320,8 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     // large batches: the MRF kernel's blocks draw tiles from per-launch counters (mrf_conv_mfma_f32.h); one
     // memset per forward zeroes them.  Below ~2000 frames no launch has enough tiles per block to use them.
     const bool dyn_tiles = h->tile_counters && (long long)B * T >= 2000 &&
-                           (int)h->stages.size() * 2 * h->cfg.num_dilations[0] <= 256;
-    if (dyn_tiles) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, 256 * sizeof(unsigned), stream));
+                           (int)h->stages.size() * 2 * h->cfg.num_dilations[0] <= kTileCounterWords;
+    if (dyn_tiles) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, kTileCounterWords * sizeof(unsigned), stream));
 
     // ---- conv_pre (hifigan_pretrained.py:124) ----
     {
@@ -362,10 +369,10 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
             TRY(prof.begin(1, (int)i, 0, 2.0 * fB * L * l.C_in * l.C_out * l.k,
                            4.0 * (fB * L * l.C_in * n_in + fB * L_out * l.C_out +
                                   (double)l.ref_w_floats + l.C_out)));
-            // split-product mode: single-input upsamplers (conv_pre output, or the folded branch mean) on split products
-            // (off by default: with the upsamplers split as well the worst observed waveform error grows from 2e-5 to
-            //  5e-5 -- still inside 1e-4, but the mode keeps the wider margin unless IRIS_HIFIGAN_S3UPS=1)
-            static const int s3_ups = [] { const char* e = getenv("IRIS_HIFIGAN_S3UPS"); return e ? atoi(e) : 0; }();
+            // split-product mode: single-input upsamplers (conv_pre output, or the folded branch mean) on split products.
+            // Off in the release library: with the upsamplers split as well the worst observed waveform error grows
+            // from 2e-5 to 5e-5 -- still inside 1e-4, but the mode keeps the wider margin (diagnostic builds: S3UPS=1).
+            const int s3_ups = IRIS_DIAG_ENV("IRIS_HIFIGAN_S3UPS", 0);
             if (s3_ups && dtype == IRIS_HIFIGAN_F32_SPLIT && a.in_act == IN_ACT_LRELU && f32s_ups_applicable(h, l, L))
                 TRY(f32s_launch_ups(h, l, a.p[0].x, a.p[0].y, B, L, stream));
             else
@@ -395,10 +402,9 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                 a.dyn_counter = dyn_tiles ? h->tile_counters + ((int)i * 2 * nd + 2 * m + half) : nullptr;
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops,
                                4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
-                static const int stop_after = [] { const char* e = getenv("IRIS_HIFIGAN_STOP_AFTER_MRF"); return e ? atoi(e) : -1; }();
-                if (stop_after >= 0 && (int)i * 100 + 2 * m + half > stop_after) { h->n_rec = prof.idx; return IRIS_HIFIGAN_OK; }   // debugging aid
-                static const int use_mrf = [] { const char* e = getenv("IRIS_HIFIGAN_MRF"); return e ? atoi(e) : 1; }();
-                static const int use_sum = [] { const char* e = getenv("IRIS_HIFIGAN_MRFSUM"); return e ? atoi(e) : 1; }();
+                const int use_mrf = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRF", 1);
+                const int use_sum = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSUM", 1);
+                const bool last_step = m == nd - 1 && half == 1;
                 bool launched = false;
                 if (dtype == IRIS_HIFIGAN_F32_SPLIT && f32s_step_applicable(h, st.C, L_out, nk)) {
                     // fp32 storage, split-bf16 products (conv_mfma_f32s.h); the branch mean is left to the consumer
@@ -409,13 +415,12 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                     }
                     // last step of the stage: the kernel folds the branch mean (written to y[0]; a lane overwrites only
                     // elements it has read itself as branch 0's residual)
-                    static const int s3_sum = [] { const char* e = getenv("IRIS_HIFIGAN_S3SUM"); return e ? atoi(e) : 1; }();
-                    const bool fold = s3_sum && m == nd - 1 && half == 1;
+                    const bool fold = IRIS_DIAG_ENV("IRIS_HIFIGAN_S3SUM", 1) && last_step;
                     TRY(f32s_launch_step(h, step, nk, B, L_out, st.C, fold ? ws + w.y[0] : nullptr, stream));
                     launched = true;
-                    if (m == nd - 1 && half == 1) prev_summed = fold;
+                    if (last_step) prev_summed = fold;
                 }
-                if (!launched && use_mrf && use_sum && m == nd - 1 && half == 1 && nk == 3) {
+                if (!launched && use_mrf && use_sum && last_step && nk == 3) {
                     // last step of the stage: the MRF kernel can form mean_j(y_j) itself.  It processes
                     // p[2], p[1], p[0]; passing the branches reversed makes that resblock 0, 1, 2 -- the
                     // reference's summation order (hifigan_pretrained.py:131-137).  The mean goes to y[0]
@@ -430,11 +435,16 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
                     }
                 }
                 if (!launched) {
-                    if (m == nd - 1 && half == 1) prev_summed = false;
+                    if (last_step) prev_summed = false;
                     if (use_mrf && mrf_kernel_applicable(a, nk)) HIP_TRY(launch_mrf_conv(a, nk, stream));
                     else                                         HIP_TRY(launch_conv(a, nk, stream));
                 }
                 TRY(prof.end());
+                if (stop.stage == (int)i && stop.step == 2 * m + half) {
+                    if (mean_in_y0) *mean_in_y0 = (last_step && prev_summed) ? 1 : 0;
+                    h->n_rec = prof.idx;
+                    return IRIS_HIFIGAN_OK;
+                }
             }
         }
         L = L_out;
@@ -442,18 +452,66 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
 
     // ---- LeakyReLU + conv_post + tanh (hifigan_pretrained.py:139-141) ----
     {
-        ConvPostLaunch a; memset(&a, 0, sizeof(a));
+        post::ConvPostLaunch a; memset(&a, 0, sizeof(a));
         const ConvLayer& l = h->post;
         if (prev_summed) { a.x[0] = ws + w.y[0]; a.n_in = 1; }
         else { for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j]; a.n_in = nk; }
         a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
-        a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope;
+        a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope; a.inv_n = 1.0f / (float)nk;
         TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
                        4.0 * (fB * L * l.C_in * nk + fB * L + (double)l.ref_w_floats + 1)));
-        HIP_TRY(launch_conv_post(a, stream));
+        HIP_TRY(post::launch_conv_post(a, stream));
         TRY(prof.end());
     }
     h->n_rec = prof.idx;
+    return IRIS_HIFIGAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                             void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
+                             int32_t dtype, void* stream_) {
+    TRY(check_forward_args(h, mel_dev, B, T, workspace_dev, dtype));
+    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
+    if (!wav_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
+    const ForwardStop none{-1, -1};
+    if (dtype == IRIS_HIFIGAN_BF16)
+        return bf16_forward(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, (hipStream_t)stream_, none, nullptr);
+    return forward_f32(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, none, nullptr);
+}
+
+int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
+                                   void* workspace_dev, uint64_t workspace_bytes, int32_t dtype,
+                                   int32_t stop_stage, int32_t stop_step, int32_t* mean_in_y0, void* stream_) {
+    TRY(check_forward_args(h, mel_dev, B, T, workspace_dev, dtype));
+    if (B == 0 || T == 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "forward_until needs a non-empty input");
+    if (stop_stage < 0 || stop_stage >= (int)h->stages.size() || stop_step < 0 || stop_step >= 2 * h->cfg.num_dilations[0])
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "no MRF step %d in stage %d", stop_step, stop_stage);
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
+    const ForwardStop stop{stop_stage, stop_step};
+    if (dtype == IRIS_HIFIGAN_BF16)
+        return bf16_forward(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream_, stop, mean_in_y0);
+    return forward_f32(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, stop, mean_in_y0);
+}
+
+int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, int32_t T, int32_t dtype,
+                                      iris_hifigan_workspace_map* out) {
+    if (!h || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    memset(out, 0, sizeof(*out));
+    if (dtype == IRIS_HIFIGAN_BF16) return bf16_workspace_map(h, B, T, out);
+    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_F32_SPLIT)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    const WsLayout w = ws_layout(h, B, T);
+    out->element_bytes = 4;
+    out->pre_offset = w.pre * 4; out->up_offset = w.up * 4; out->total_bytes = w.total * 4;
+    for (int j = 0; j < h->cfg.num_kernels; ++j) { out->y_offset[j] = w.y[j] * 4; out->xt_offset[j] = w.xt[j] * 4; }
     return IRIS_HIFIGAN_OK;
 }
 
@@ -540,12 +598,54 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
     wv[(size_t)k * C_in] = bias_host[0];
     DevBuf wb;
     HIP_TRY(wb.upload(wv));
-    ConvPostLaunch a; memset(&a, 0, sizeof(a));
+    post::ConvPostLaunch a; memset(&a, 0, sizeof(a));
     a.x[0] = x0_dev; a.n_in = 1;
     if (x1_dev) { a.x[1] = x1_dev; a.x[2] = x2_dev; a.n_in = 3; }
     a.w = wb.p; a.bias = wb.p + (size_t)k * C_in; a.y = y_dev;
-    a.B = B; a.L = L; a.C = C_in; a.k = k; a.slope = slope;
-    HIP_TRY(launch_conv_post(a, stream));
+    a.B = B; a.L = L; a.C = C_in; a.k = k; a.slope = slope; a.inv_n = 1.0f / (float)a.n_in;
+    HIP_TRY(post::launch_conv_post(a, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* w_host, const float* const* bias_host,
+                                 const float* const* res_dev, float* const* y_dev, float* mean_dev,
+                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, int32_t plan, void* stream_) {
+    if (!x_dev || !w_host || !bias_host || !k || !dil || (!y_dev && !mean_dev))
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 3) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
+    const int nk = 3;
+    for (int j = 0; j < nk; ++j) {
+        if (!x_dev[j] || !w_host[j] || !bias_host[j] || (!mean_dev && !y_dev[j])) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
+        if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad branch kernel size / dilation");
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    DevBuf wb[3];
+    size_t boff[3];
+    ConvLaunch a; init_launch(a);
+    for (int j = 0; j < nk; ++j) {
+        std::vector<float> packed(packed_conv1d_floats(C, C, k[j]) + ((size_t)C + 3 & ~(size_t)3));
+        pack_conv1d_weights(w_host[j], C, C, k[j], packed.data());
+        boff[j] = packed_conv1d_floats(C, C, k[j]);
+        memcpy(packed.data() + boff[j], bias_host[j], sizeof(float) * C);
+        HIP_TRY(wb[j].upload(packed));
+        ConvProblem& p = a.p[j];
+        p.x = x_dev[j]; p.res = res_dev ? res_dev[j] : nullptr; p.y = y_dev ? y_dev[j] : nullptr;
+        p.wp = (const f32x4*)wb[j].p; p.bias = wb[j].p + boff[j];
+        p.ks = k[j]; p.dil = dil[j]; p.pad_left = dil[j] * (k[j] - 1) / 2;
+    }
+    a.B = B; a.L_in = L; a.L_out = L; a.C_in = C; a.C_out = C; a.n_idx = L; a.in_act = IN_ACT_LRELU; a.slope = slope;
+    if (mean_dev) {
+        // the summing step takes the branches reversed so that they are processed as resblock 0, 1, 2 (see forward)
+        std::swap(a.p[0], a.p[2]);
+        a.sum_y = mean_dev; a.sum_div = (float)nk;
+        for (int j = 0; j < nk; ++j) if (!a.p[j].y) a.p[j].y = mean_dev;     // never written; keeps descriptors valid
+    }
+    if (!mrf_kernel_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the MRF kernel");
+    const int force = plan == 0 ? -1 : plan - 1;
+    if (mean_dev && force == 2) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block mode cannot form the mean");
+    HIP_TRY(launch_mrf_conv(a, nk, stream, force));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
 }
@@ -560,6 +660,7 @@ struct iris_postnet_handle {
     std::vector<ConvLayer> layers;
     float* blob = nullptr;
     size_t blob_floats = 0;
+    int device = 0;
 };
 
 extern "C" {
@@ -600,7 +701,8 @@ int32_t iris_postnet_create(int32_t n_mels, int32_t num_layers, int32_t channels
         memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
         src += l.C_out;
     }
-    hipError_t e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
+    hipError_t e = hipGetDevice(&h->device);
+    if (e == hipSuccess) e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (h->blob) (void)hipFree(h->blob);
@@ -640,6 +742,8 @@ int32_t iris_postnet_forward(iris_postnet_handle* h, const void* mel_dev, int32_
     if (workspace_bytes < need)
         return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
                     (unsigned long long)workspace_bytes, (unsigned long long)need);
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
     hipStream_t stream = (hipStream_t)stream_;
     const size_t frames = (size_t)B * T;
     const size_t hid = (frames * h->channels + 63) & ~(size_t)63;

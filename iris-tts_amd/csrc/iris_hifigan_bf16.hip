@@ -7,6 +7,7 @@
 #include "generator_internal.h"
 #include "conv_mfma_bf16.h"
 #include "conv_mfma_f32s.h"
+#include "conv_post.h"
 
 namespace iris {
 
@@ -165,8 +166,17 @@ uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T) {
     return ws16_layout(h, B, T).total * sizeof(uint16_t);
 }
 
+int bf16_workspace_map(const iris_hifigan_handle* h, int B, int T, iris_hifigan_workspace_map* out) {
+    const Ws16 w = ws16_layout(h, B, T);
+    out->element_bytes = 2;
+    out->pre_offset = w.pre * 2; out->up_offset = w.up * 2; out->total_bytes = w.total * 2;
+    for (int j = 0; j < h->cfg.num_kernels; ++j) { out->y_offset[j] = w.y[j] * 2; out->xt_offset[j] = w.xt[j] * 2; }
+    return IRIS_HIFIGAN_OK;
+}
+
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
-                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream) {
+                 void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream, const ForwardStop& stop,
+                 int32_t* mean_in_y0) {
     if (!h->blob16)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 path needs channel counts that are multiples of 8 and at most %d MRF kernels", kMaxGroup);
     const Ws16 w = ws16_layout(h, B, T);
@@ -248,6 +258,11 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops, 2.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
                 HIP_TRY(launch_conv_bf16(a, nk, stream));
                 TRY(prof.end());
+                if (stop.stage == (int)i && stop.step == 2 * m + half) {
+                    if (mean_in_y0) *mean_in_y0 = 0;
+                    h->n_rec = prof.idx;
+                    return IRIS_HIFIGAN_OK;
+                }
             }
         }
         L = L_out;
@@ -255,15 +270,26 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
 
     // ---- LeakyReLU + conv_post + tanh (hifigan_pretrained.py:139-141): bf16 in, fp32 waveform out ----
     {
-        PostLaunch a; memset(&a, 0, sizeof(a));
         const ConvLayer& l = h->post;
-        for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
-        a.n_in = nk; a.inv_n = 1.0f / (float)nk;
-        a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
-        a.B = B; a.L = L; a.C = l.C_in; a.k = l.k; a.slope = slope;
         TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
                        2.0 * fB * L * l.C_in * nk + 4.0 * (fB * L + (double)l.ref_w_floats + 1)));
-        HIP_TRY(launch_conv_post_bf16(a, stream));
+        const int C = l.C_in;
+        if (C == 8 || C == 16 || C == 32 || C == 64) {
+            // 16-byte staging, batch folded into the grid (conv_post.h); same arithmetic as the kernel below
+            post::ConvPostLaunch a; memset(&a, 0, sizeof(a));
+            for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+            a.n_in = nk; a.inv_n = 1.0f / (float)nk;
+            a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
+            a.B = B; a.L = L; a.C = C; a.k = l.k; a.slope = slope;
+            HIP_TRY(post::launch_conv_post_t<true>(a, stream));
+        } else {
+            PostLaunch a; memset(&a, 0, sizeof(a));
+            for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+            a.n_in = nk; a.inv_n = 1.0f / (float)nk;
+            a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
+            a.B = B; a.L = L; a.C = C; a.k = l.k; a.slope = slope;
+            HIP_TRY(launch_conv_post_bf16(a, stream));
+        }
         TRY(prof.end());
     }
     h->n_rec = prof.idx;

@@ -467,11 +467,7 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
 // How a grouped MRF step is spread over the chip.
 struct MrfPlan { int MT; bool zpar; long long n_tiles; long long grid; int zb1, zb2; };
 
-inline int mrf_cu_count() {
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev);
-                                 (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    return n_cu;
-}
+inline int mrf_cu_count() { return device_cu_count(); }
 
 // Tile-serial mode: a persistent grid of at most `per_cu` blocks per CU; every block runs the three branches of its
 // tiles (equal cost) and the grid is evened out so that every block walks the same number of tiles (+-1): 1000
@@ -481,9 +477,11 @@ inline int mrf_cu_count() {
 // block counts are the ones that minimise that under nb_11 + nb_7 + nb_3 <= slots.  The mode with the smaller
 // estimate is taken (half-height tiles and zpar carry a few per cent overhead): zpar wins when there are few
 // tiles or their number falls between multiples of the slot count (T = 100 ... 400 frames at batch 1).
-inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar) {
-    static const int per_cu_env = [] { const char* e = getenv("IRIS_HIFIGAN_PERCU"); return e ? atoi(e) : 0; }();
-    static const int plan_env = [] { const char* e = getenv("IRIS_HIFIGAN_MRFPLAN"); return e ? atoi(e) : -1; }();  // diagnostics: 0 MT2, 1 MT1, 2 MT1+zpar, 3 the round-1 rule
+// `force` (>= 0: the single-step test entry point, or the diagnostic build's IRIS_HIFIGAN_MRFPLAN) pins the mode:
+// 0 full-height tiles, 1 half-height tiles, 2 half-height + one branch per block, 3 the round-1 rule.
+inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
+    const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
+    const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", -1);
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     const int n_cu = mrf_cu_count();
     const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
@@ -537,7 +535,7 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar) {
     return pl;
 }
 
-inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
+inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int force_plan = -1) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     a.n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     a.Gp = packed_groups(a.C_in);
@@ -545,13 +543,12 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     a.z_serial = 1;
     a.nz_serial = nz;
     a.nz = 1;
-    static const int ablate_env = [] { const char* e = getenv("IRIS_HIFIGAN_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = ablate_env;
-    const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr);
+    a.ablate = IRIS_DIAG_ENV("IRIS_HIFIGAN_ABLATE", 0);
+    const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
     const int T_BLK = t.WT * pl.MT * 32;
     const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;   // + next-tile word
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
-    static const int dyn_env = [] { const char* e = getenv("IRIS_HIFIGAN_DYNTILES"); return e ? atoi(e) : 1; }();
+    const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
     if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
     a.zb1 = pl.zb1; a.zb2 = pl.zb2;
     const long long n_tiles = pl.n_tiles, g = pl.grid;

@@ -37,7 +37,13 @@ def require_gpu() -> torch.device:
 
 
 class GeneratorEngine:
-    """One HiFiGAN generator resident on one GPU."""
+    """One HiFiGAN generator resident on one GPU.
+
+    One forward in flight per engine: the engine owns ONE activation workspace (every forward and every
+    captured hipGraph of it writes there) and the native handle owns per-forward device state, so forwards of
+    one engine must be stream-ordered -- issue them on one stream, or build one engine per stream.  The native
+    calls select the engine's device themselves (``include/iris_hifigan.h``), so an engine may live on a GPU
+    that is not the caller's current device."""
 
     def __init__(self, cfg: GeneratorConfig, state_dict: Mapping[str, object],
                  device: Optional[torch.device] = None, dtype: Optional[str] = None):
@@ -63,6 +69,7 @@ class GeneratorEngine:
         self.hop_length = int(hop.value)
         self._workspace: Optional[torch.Tensor] = None
         self._graphs: dict = {}
+        self._profiling = False
 
     # -- lifetime ----------------------------------------------------------------------------
     def close(self) -> None:
@@ -91,6 +98,12 @@ class GeneratorEngine:
             self._workspace = None  # release before growing
             self._workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
         return self._workspace
+
+    def release_workspace(self) -> None:
+        """Frees the activation workspace (it grows to the largest shape seen: 229 KB per mel frame in fp32) and the
+        captured graphs that point into it; the next forward allocates what it needs."""
+        self._graphs = {}
+        self._workspace = None
 
     def forward(self, mel: torch.Tensor, out: Optional[torch.Tensor] = None, dtype: Optional[str] = None) -> torch.Tensor:
         """mel: fp32 device tensor [B, in_channels, T] -> waveform fp32 [B, hop*T] (asynchronous on
@@ -144,7 +157,9 @@ class GeneratorEngine:
             self._get_workspace(self.workspace_bytes(batch, frames, dtype))     # allocate before capture
             ws_ptr = self._workspace.data_ptr()
             static_in.copy_(mel)
-            self.set_profiling(False)
+            was_profiling = self._profiling
+            if was_profiling:
+                self.set_profiling(False)        # no event records inside a capture
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                                # warm-up outside capture
@@ -155,6 +170,8 @@ class GeneratorEngine:
                 self.forward(static_in, out=static_out, dtype=dtype)
             entry = (graph, static_in, static_out, ws_ptr)
             self._graphs[key] = entry
+            if was_profiling:
+                self.set_profiling(True)
         graph, static_in, static_out, ws_ptr = entry
         if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
             # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
@@ -167,6 +184,46 @@ class GeneratorEngine:
     # -- profiling (bench.py roofline leg) -----------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:
         _native.check("iris_hifigan_set_profiling", self.lib.iris_hifigan_set_profiling(self._handle, int(enabled)))
+        self._profiling = bool(enabled)
+
+    # -- intermediates (parity tests) ------------------------------------------------------------
+    def forward_until(self, mel: torch.Tensor, stage: int, step: int, dtype: Optional[str] = None) -> dict:
+        """Runs the forward up to and including MRF step ``step`` of upsample stage ``stage`` and returns the
+        intermediates that are then in the workspace, as channels-first numpy arrays like the reference's
+        tensors: ``pre`` [B, C0, T], ``up`` [B, C, L] (the stage's ConvTranspose1d output), ``y`` / ``xt``
+        (lists per ResBlock branch, [B, C, L]) and ``mean_in_y0`` (True when the stage's last step already
+        stored the MRF mean, hifigan_pretrained.py:131-137, in ``y[0]``).  bf16 storage is widened to fp32."""
+        dtype = dtype or self.default_dtype
+        code = _dtype_code(dtype)
+        mel = mel.to(device=self.device, dtype=torch.float32).contiguous()
+        batch, _, frames = mel.shape
+        ws = self._get_workspace(self.workspace_bytes(batch, frames, dtype))
+        wmap = _native.WorkspaceMap()
+        _native.check("iris_hifigan_workspace_layout", self.lib.iris_hifigan_workspace_layout(
+            self._handle, batch, frames, code, ctypes.byref(wmap)))
+        folded = ctypes.c_int32(0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _native.check("iris_hifigan_forward_until", self.lib.iris_hifigan_forward_until(
+            self._handle, ctypes.c_void_p(mel.data_ptr()), batch, frames, ctypes.c_void_p(ws.data_ptr()),
+            ctypes.c_uint64(ws.numel()), code, stage, step, ctypes.byref(folded), ctypes.c_void_p(stream)))
+        torch.cuda.synchronize(self.device)
+        tdt = torch.float32 if wmap.element_bytes == 4 else torch.bfloat16
+        length, ch = frames, self.cfg.upsample_initial_channel
+        for i in range(stage + 1):
+            length *= self.cfg.upsample_rates[i]
+            ch //= 2
+
+        def view(off: int, L: int, C: int) -> np.ndarray:
+            n = batch * L * C * wmap.element_bytes
+            t = ws[off:off + n].view(tdt).reshape(batch, L, C)
+            return t.float().cpu().numpy().transpose(0, 2, 1).copy()
+
+        nk = self.cfg.num_kernels
+        return {"pre": view(wmap.pre_offset, frames, self.cfg.upsample_initial_channel),
+                "up": view(wmap.up_offset, length, ch),
+                "y": [view(wmap.y_offset[j], length, ch) for j in range(nk)],
+                "xt": [view(wmap.xt_offset[j], length, ch) for j in range(nk)],
+                "mean_in_y0": bool(folded.value)}
 
     def read_profile(self) -> List[dict]:
         """Per-launch records of every forward since set_profiling(True); the stream must have

@@ -14,7 +14,7 @@ from typing import Optional
 MAX_STAGES = 8
 MAX_KERNELS = 8
 MAX_DILATIONS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
@@ -70,6 +70,20 @@ class LaunchRecord(ctypes.Structure):
     ]
 
 
+class WorkspaceMap(ctypes.Structure):
+    """``iris_hifigan_workspace_map``"""
+
+    _fields_ = [
+        ("pre_offset", ctypes.c_uint64),
+        ("up_offset", ctypes.c_uint64),
+        ("y_offset", ctypes.c_uint64 * MAX_KERNELS),
+        ("xt_offset", ctypes.c_uint64 * MAX_KERNELS),
+        ("total_bytes", ctypes.c_uint64),
+        ("element_bytes", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/iris_hifigan.h
 _c = ctypes
 _vp, _i32, _u64, _f = _c.c_void_p, _c.c_int32, _c.c_uint64, _c.c_float
@@ -82,12 +96,16 @@ SYMBOLS = {
     "iris_hifigan_destroy": (_i32, [_vp]),
     "iris_hifigan_workspace_bytes": (_i32, [_vp, _i32, _i32, _i32, _c.POINTER(_u64)]),
     "iris_hifigan_forward": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _i32, _vp]),
+    "iris_hifigan_workspace_layout": (_i32, [_vp, _i32, _i32, _i32, _c.POINTER(WorkspaceMap)]),
+    "iris_hifigan_forward_until": (_i32, [_vp, _vp, _i32, _i32, _vp, _u64, _i32, _i32, _i32, _c.POINTER(_i32), _vp]),
     "iris_hifigan_hop_length": (_i32, [_vp, _c.POINTER(_i32)]),
     "iris_hifigan_set_profiling": (_i32, [_vp, _i32]),
     "iris_hifigan_read_profile": (_i32, [_vp, _c.POINTER(LaunchRecord), _i32, _c.POINTER(_i32)]),
     "iris_hifigan_op_conv1d": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _i32, _vp]),
     "iris_hifigan_op_conv_transpose1d": (_i32, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv_post": (_i32, [_vp, _vp, _vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
+    "iris_hifigan_op_mrf_step": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_vp), _c.POINTER(_vp), _vp,
+                                       _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _i32, _vp]),
     "iris_hifigan_op_conv1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv_transpose1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv1d_f32s": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp]),

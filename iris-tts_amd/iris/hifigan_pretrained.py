@@ -145,12 +145,33 @@ class HiFiGANModel(nn.Module):
         if eng is not None:
             eng.close()
         self.__dict__["_engine"] = None
+        self.__dict__["_packed_from"] = None
+
+    def invalidate(self) -> None:
+        """Drops the packed device copy of the weights; the next forward folds and repacks the current
+        parameters.  Tracked in-place edits (``with torch.no_grad(): p.copy_(...)``, ``p.mul_(...)``,
+        ``load_state_dict``) are noticed through the tensors' version counters and repack by themselves; edits
+        that bypass the counters -- ``p.data.copy_(...)`` (``.data`` has a counter of its own by design), writing
+        through ``p.numpy()`` -- must be followed by ``invalidate()``, or the GPU keeps running the old weights."""
+        self._drop_engine()
+
+    def _parameter_versions(self):
+        tensors = self.__dict__.get("_packed_from")
+        if tensors is None:
+            return None
+        return tuple(t._version for t in tensors)
 
     def engine(self) -> GeneratorEngine:
+        if self._engine is not None and self._parameter_versions() != self.__dict__.get("_packed_versions"):
+            logger.info("HiFiGAN parameters changed since they were packed for the GPU: repacking")
+            self._drop_engine()
         if self._engine is None:
             device = getattr(self, "_target_device", None) or require_gpu()
+            tensors = list(self.state_dict(keep_vars=True).values())
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
             self._engine = GeneratorEngine(self.config, sd, device)
+            self.__dict__["_packed_from"] = tensors
+            self.__dict__["_packed_versions"] = tuple(t._version for t in tensors)
         return self._engine
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

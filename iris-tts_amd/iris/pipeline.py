@@ -13,21 +13,25 @@ from typing import Callable, Iterator, Optional
 import numpy as np
 import torch
 
-from .streaming import RECEPTIVE_FIELD_FRAMES, StreamingVocoder
+from .streaming import StreamingVocoder
 
 
 class MelToWavePipeline:
     """``postnet``: an ``iris.postnet.PostNet`` (or any callable mapping a device mel ``[B, n_mels, T]`` to a
     refined one), or None to vocode the mel as it is.  ``vocode``: ``GeneratorEngine.forward`` (or any callable
-    ``[B, n_mels, W] -> [B, hop*W]``)."""
+    ``[B, n_mels, W] -> [B, hop*W]``).  ``config``: the generator's ``GeneratorConfig`` -- hop length and the
+    minimal halo are derived from it (V1 values when omitted; ``vocode.__self__.cfg`` is picked up when ``vocode``
+    is a bound ``GeneratorEngine.forward``)."""
 
     def __init__(self, postnet: Optional[Callable], vocode: Callable, device: Optional[torch.device] = None,
-                 hop_length: int = 256, chunk_frames: int = 256, halo_frames: int = RECEPTIVE_FIELD_FRAMES,
-                 group_chunks: int = 1):
+                 hop_length: Optional[int] = None, chunk_frames: int = 256, halo_frames: Optional[int] = None,
+                 group_chunks: int = 1, config=None):
         self.postnet = postnet
         self.device = device
+        if config is None:
+            config = getattr(getattr(vocode, "__self__", None), "cfg", None)
         self.streamer = StreamingVocoder(vocode, hop_length=hop_length, chunk_frames=chunk_frames,
-                                         halo_frames=halo_frames, group_chunks=group_chunks)
+                                         halo_frames=halo_frames, group_chunks=group_chunks, config=config)
 
     def refine(self, mel) -> torch.Tensor:
         """Host or device mel ``[B, n_mels, T]`` -> refined device mel (one PostNet pass over the whole utterance:

@@ -14,9 +14,39 @@ callable -- the GPU engine in production, the CPU oracle in the tests.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, Iterator, List
+from typing import Callable, Iterator, List, Optional
 
-RECEPTIVE_FIELD_FRAMES = 13  # ceil(12.64); V1 config
+RECEPTIVE_FIELD_FRAMES = 13  # ceil(12.64); V1 config (== receptive_field_frames(GeneratorConfig()))
+
+
+def receptive_field_frames(cfg) -> int:
+    """Mel frames of context on either side that can reach the samples of one frame, for any generator
+    configuration (``GeneratorConfig`` or an object with the same attributes).
+
+    Exact interval propagation from the output back to the mel through the layers of
+    ``HiFiGANModel.forward`` (src/iris/hifigan_pretrained.py:123-143): a Conv1d(k, dilation d, 'same')
+    widens an index interval by d*(k-1)/2 on both sides; ConvTranspose1d(k, stride u, padding p=(k-u)/2)
+    sends input i to outputs i*u - p + [0, k), so outputs [a, b] need inputs
+    [ceil((a + p - k + 1)/u), floor((b + p)/u)]; a ResBlock chains, per dilation d, Conv1d(k, d) and
+    Conv1d(k, 1) (:64-71), and the MRF takes the widest branch.  13 for the V1 configuration."""
+    hop = 1
+    for u in cfg.upsample_rates:
+        hop *= int(u)
+    c = 4096                                    # any frame far from the edges
+    a, b = c * hop, c * hop + hop - 1
+    post = (int(getattr(cfg, "post_kernel_size", 7)) - 1) // 2
+    a, b = a - post, b + post
+    branches = list(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes))
+    for i in reversed(range(len(cfg.upsample_rates))):
+        ext = max(sum((int(k) - 1) // 2 * (int(d) + 1) for d in dils) for k, dils in branches)
+        a, b = a - ext, b + ext
+        u, k = int(cfg.upsample_rates[i]), int(cfg.upsample_kernel_sizes[i])
+        pad = (k - u) // 2
+        a = -((-(a + pad - (k - 1))) // u)     # ceil
+        b = (b + pad) // u
+    pre = (int(getattr(cfg, "pre_kernel_size", 7)) - 1) // 2
+    a, b = a - pre, b + pre
+    return max(c - a, b - c, 0)
 
 
 @dataclass(frozen=True)
@@ -50,14 +80,24 @@ class StreamingVocoder:
     inputs/outputs may be torch tensors or numpy arrays -- they are only sliced along the last axis.
     """
 
-    def __init__(self, forward: Callable, hop_length: int = 256, chunk_frames: int = 256,
-                 halo_frames: int = RECEPTIVE_FIELD_FRAMES, group_chunks: int = 1):
-        if halo_frames < RECEPTIVE_FIELD_FRAMES:
+    def __init__(self, forward: Callable, hop_length: Optional[int] = None, chunk_frames: int = 256,
+                 halo_frames: Optional[int] = None, group_chunks: int = 1, config=None):
+        """``config``: the generator's ``GeneratorConfig``; when given, the hop length and the minimal halo are
+        computed from it (``receptive_field_frames``), otherwise the V1 values (256, 13) are assumed -- pass the
+        config for any other architecture, or the seams silently differ from the one-shot output."""
+        need = receptive_field_frames(config) if config is not None else RECEPTIVE_FIELD_FRAMES
+        if halo_frames is None:
+            halo_frames = need
+        if halo_frames < need:
             raise ValueError(
                 f"halo_frames={halo_frames} is smaller than the generator's receptive field "
-                f"({RECEPTIVE_FIELD_FRAMES} frames): chunk seams would differ from the one-shot output")
+                f"({need} frames): chunk seams would differ from the one-shot output")
         if group_chunks < 1:
             raise ValueError("group_chunks >= 1 is required")
+        if hop_length is None:
+            hop_length = int(config.hop_length) if config is not None else 256
+        elif config is not None and hop_length != int(config.hop_length):
+            raise ValueError(f"hop_length={hop_length} does not match the configuration's {config.hop_length}")
         self.forward = forward
         self.hop_length = hop_length
         self.chunk_frames = chunk_frames

@@ -170,6 +170,12 @@ class HiFiGANGenerator:
             self._engine.close()
         self._engine = None
 
+    def invalidate(self) -> None:
+        """Drops the packed device copy of the weights.  ``set_weights_dict`` / ``load_weights`` do this
+        themselves; call it after editing the arrays in ``self.weights`` in place (numpy arrays carry no
+        version counter, so such edits cannot be noticed): the next call repacks the current values."""
+        self._drop_engine()
+
     def engine(self) -> GeneratorEngine:
         if self._engine is None:
             self._engine = GeneratorEngine(self.config, self.reference_state_dict(), require_gpu())

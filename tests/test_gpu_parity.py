@@ -141,6 +141,151 @@ def test_conv_post_matches_oracle(lib, B, L, C, k, three):
 
 
 # ------------------------------------------------------------------------------------------------
+# the hot kernel on its own: one grouped MRF step (mrf_conv_mfma_f32_kernel) in each of its launch modes
+# ------------------------------------------------------------------------------------------------
+MRF_STEP_CASES = [
+    # (B, L, C, dils, residual)   every tile configuration of the kernel (C <= 32 / <= 64 / > 64), ragged lengths
+    (1, 700, 32, (5, 5, 5), False), (2, 333, 32, (1, 1, 1), True), (1, 520, 64, (3, 3, 3), True),
+    (1, 200, 128, (5, 5, 5), True), (2, 70, 256, (1, 1, 1), True), (1, 97, 256, (3, 3, 3), False),
+]
+
+
+def _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean):
+    """Runs iris_hifigan_op_mrf_step; returns the three branch outputs [B,C,L] or the mean."""
+    ks = (3, 7, 11)
+    xd = [_cl(x) for x in xs]
+    rd = [_cl(r) for r in rs] if rs is not None else None
+    yd = [torch.full((B, L, C), float("nan"), device="cuda") for _ in range(3)]
+    md = torch.full((B, L, C), float("nan"), device="cuda") if mean else None
+    vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
+    status = lib.iris_hifigan_op_mrf_step(
+        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in ws]), fp3(*[_fp(b) for b in bs]),
+        vp3(*[t.data_ptr() for t in rd]) if rd is not None else None, vp3(*[t.data_ptr() for t in yd]),
+        md.data_ptr() if mean else None, B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils),
+        0.1, plan, None)
+    return status, ([t.cpu().numpy().transpose(0, 2, 1) for t in yd] if not mean else md.cpu().numpy().transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("plan", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,L,C,dils,use_res", MRF_STEP_CASES)
+def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
+    """One conv step of the three ResBlock branches (k = 3/7/11; hifigan_pretrained.py:64-71) through the persistent
+    MRF kernel, in the library's own plan (0), with full-height tiles (1), half-height tiles (2) and one branch per
+    block (3), against the numpy oracle's conv1d_np.  All plans run the same fmaf chains: they must agree bit for bit."""
+    rng = np.random.default_rng(C * 7 + L + plan)
+    ks = (3, 7, 11)
+    xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    ws = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    bs = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    rs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks] if use_res else None
+    status, got = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean=False)
+    _check("op_mrf_step", status)
+    for j in range(3):
+        want = orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), ws[j], bs[j], dils[j])
+        if use_res:
+            want = want + rs[j]
+        assert np.isfinite(got[j]).all()
+        assert np.abs(got[j] - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max()), (j, plan)
+    if plan != 0:
+        _, auto = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, 0, mean=False)
+        for j in range(3):
+            assert np.array_equal(auto[j], got[j]), (j, plan)
+
+
+@pytest.mark.parametrize("plan", [0, 1, 2])
+@pytest.mark.parametrize("B,L,C", [(1, 700, 32), (1, 300, 64), (2, 130, 128), (1, 90, 256)])
+def test_mrf_summing_step_matches_oracle(lib, B, L, C, plan):
+    """The last step of a stage stores only ((y0 + y1) + y2) / 3 (hifigan_pretrained.py:131-137, the reference's
+    order and a true division)."""
+    rng = np.random.default_rng(C + L + plan)
+    ks, dils = (3, 7, 11), (1, 1, 1)
+    xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    ws = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    bs = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    rs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    status, got = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean=True)
+    _check("op_mrf_step", status)
+    ys = [(orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), ws[j], bs[j], 1) + rs[j]).astype(np.float32) for j in range(3)]
+    want = ((ys[0] + ys[1]) + ys[2]) / np.float32(3)
+    assert np.abs(got - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max())
+    # and it is bit for bit what the separate branch outputs give when summed in the reference's order
+    _, sep = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean=False)
+    assert np.array_equal(got, ((sep[0] + sep[1]) + sep[2]) / np.float32(3))
+
+
+def test_mrf_step_rejects_what_the_kernel_cannot_take(lib):
+    x = [np.zeros((1, 30, 40), np.float32)] * 3
+    w = [np.zeros((30, 30, k), np.float32) for k in (3, 7, 11)]
+    b = [np.zeros(30, np.float32)] * 3
+    status, _ = _mrf_step(lib, x, w, b, None, 1, 40, 30, (1, 1, 1), 0, mean=False)        # C % 4 != 0
+    assert status == 4                                                                     # IRIS_HIFIGAN_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------
+# intermediates of a whole forward against the reference's own per-layer taps
+# ------------------------------------------------------------------------------------------------
+def test_generator_intermediates_match_reference_taps(golden, case_setup, dev):
+    """conv_pre, every ConvTranspose1d output and every MRF output of a forward, read out of the workspace
+    (iris_hifigan_forward_until), against the activations hooked out of the REFERENCE for the same weights and mel
+    (tests/golden/v1_default_T4_taps.npz): a wrong layer shows up where it happens, not only as a waveform error."""
+    from iris._engine import GeneratorEngine
+    cfg, sd = case_setup("v1_default_T4_taps")
+    g = golden("v1_default_T4_taps")
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(g["mel"]).to(dev)
+    last = 2 * len(cfg.resblock_dilation_sizes[0]) - 1
+    for i in range(cfg.num_upsamples):
+        taps = eng.forward_until(mel, i, last)
+        if i == 0:
+            assert np.abs(taps["pre"] - g["conv_pre"]).max() <= TOL_LAYER * np.abs(g["conv_pre"]).max()
+        assert np.abs(taps["up"] - g[f"ups_{i}"]).max() <= TOL_LAYER * max(1.0, np.abs(g[f"ups_{i}"]).max()), i
+        y = taps["y"]
+        mrf = y[0] if taps["mean_in_y0"] else ((y[0] + y[1]) + y[2]) / np.float32(3)
+        assert np.abs(mrf - g[f"mrf_{i}"]).max() <= TOL_LAYER * max(1.0, np.abs(g[f"mrf_{i}"]).max()), i
+    eng.close()
+
+
+@pytest.mark.parametrize("T", [4, 300])
+def test_generator_intermediates_match_oracle_every_step(T, dev):
+    """Every MRF step of every stage (xt after the dilated conv, y after conv + residual) against the numpy oracle's
+    ResBlock arithmetic applied to the GPU's own stage input -- at T = 4 (one branch per block) and T = 300 (persistent
+    tiles, mean folded by the last step)."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    folded = orc.fold_state_dict(sd)
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(seeded_mel(31, 1, T)).to(dev)
+    nd = len(cfg.resblock_dilation_sizes[0])
+    stage = 3 if T == 4 else 1            # (one stage is enough at T = 300: the oracle's fp64 loops are slow)
+    x = eng.forward_until(mel, stage, 0)["up"]
+    cur = [x, x, x]
+    for m in range(nd):
+        taps = eng.forward_until(mel, stage, 2 * m)
+        for j, d in enumerate(cfg.resblock_dilation_sizes):
+            pfx = f"resblocks.{stage * cfg.num_kernels + j}"
+            want = orc.conv1d_np(orc.lrelu_np(cur[j], 0.1), folded[f"{pfx}.convs1.{m}.weight"], folded[f"{pfx}.convs1.{m}.bias"], d[m])
+            assert np.abs(taps["xt"][j] - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max()), (m, j)
+        xt = taps["xt"]
+        taps = eng.forward_until(mel, stage, 2 * m + 1)
+        nxt = []
+        for j in range(cfg.num_kernels):
+            pfx = f"resblocks.{stage * cfg.num_kernels + j}"
+            want = orc.conv1d_np(orc.lrelu_np(xt[j], 0.1), folded[f"{pfx}.convs2.{m}.weight"], folded[f"{pfx}.convs2.{m}.bias"], 1) + cur[j]
+            nxt.append(want.astype(np.float32))
+        if taps["mean_in_y0"]:
+            assert m == nd - 1
+            want = ((nxt[0] + nxt[1]) + nxt[2]) / np.float32(3)
+            assert np.abs(taps["y"][0] - want).max() <= TOL_LAYER * max(1.0, np.abs(want).max())
+        else:
+            for j in range(cfg.num_kernels):
+                assert np.abs(taps["y"][j] - nxt[j]).max() <= TOL_LAYER * max(1.0, np.abs(nxt[j]).max()), (m, j)
+            cur = taps["y"]
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
 # whole generator
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["v1_default_T4_taps", "v1_default_B2_T16", "v1_amplified_T24", "small_cfg_B3_T19"])
@@ -261,6 +406,48 @@ def test_config3_batch32_properties(dev):
     for b in (5, 30):
         want = orc.generator_forward_torch(folded, mel_np[b:b + 1]).numpy()[0, 0]
         assert np.abs(full[b].cpu().numpy() - want).max() <= TOL_WAV
+    eng.close()
+
+
+@pytest.mark.parametrize("B,T", [(32, 1000), (256, 100)])
+def test_config4_per_rank_and_short_shapes(B, T, dev):
+    """configs[3] (global batch 256 over 8 GPUs): the per-rank workload at N = 8 (32 x 1000 frames) and the
+    whole global batch at the grid's shortest length (256 x 100) on one GPU -- finite, inside tanh's range, items
+    0 / mid / last against the oracle, and every checked item bit-identical to the same mel vocoded alone."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    mel_np = seeded_mel(1004, B, T, log_mel=True)
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(mel_np).to(dev)
+    full = eng.forward(mel).clone()
+    assert full.shape == (B, 256 * T) and torch.isfinite(full).all() and full.abs().max() <= 1.0
+    assert torch.equal(eng.forward(mel), full)
+    folded = orc.to_torch_folded(sd)
+    for b in (0, B // 2, B - 1):
+        alone = eng.forward(mel[b:b + 1].contiguous())
+        assert torch.equal(alone[0], full[b]), b
+        want = orc.generator_forward_torch(folded, mel_np[b:b + 1]).numpy()[0, 0]
+        assert np.abs(full[b].cpu().numpy() - want).max() <= TOL_WAV, b
+    eng.close()
+
+
+def test_engine_on_a_device_that_is_not_current(dev):
+    """The native calls select the engine's device themselves: with two or more GPUs the engine runs on cuda:1 while
+    cuda:0 is current; on a one-GPU box the same code path runs with the guard as a no-op."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    target = torch.device("cuda", 1 if torch.cuda.device_count() > 1 else 0)
+    torch.cuda.set_device(0)
+    eng = GeneratorEngine(cfg, sd, target)
+    mel_np = seeded_mel(8, 1, 30)
+    got = eng.forward(torch.from_numpy(mel_np).to(target))
+    assert torch.cuda.current_device() == 0 and got.device == target
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel_np).numpy()[:, 0, :]
+    assert np.abs(got.cpu().numpy() - want).max() <= TOL_WAV
     eng.close()
 
 

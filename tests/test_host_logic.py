@@ -186,9 +186,10 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iris_hifigan_abi_version() == 1
+    assert lib.iris_hifigan_abi_version() == _native.ABI_VERSION == 2
     assert ctypes.sizeof(_native.Config) == 4 * (3 + 8 + 8 + 1 + 8 + 8 + 64 + 2) + 4
     assert ctypes.sizeof(_native.LaunchRecord) == 40
+    assert ctypes.sizeof(_native.WorkspaceMap) == 8 * (2 + 8 + 8 + 1) + 8
 
 
 def test_cabi_argument_validation_without_gpu():
@@ -226,3 +227,90 @@ def test_product_never_imports_the_oracle():
         if path.suffix in (".py", ".hip", ".h", ".cpp") and path.is_file():
             text = path.read_text()
             assert "import oracle" not in text and "from oracle" not in text and "hifigan_oracle" not in text, path
+
+
+def test_release_library_reads_no_diagnostic_switch():
+    """A shipped library must not change what it computes because of a stray environment variable: every
+    diagnostic switch (IRIS_HIFIGAN_*, IRIS_B16_*, IRIS_S3_*, IRIS_MRF_*) is compiled in only with -DIRIS_MRF_DIAG
+    (csrc/diag_env.h), so none of their names may occur in the release .so, and it must not import getenv at all."""
+    import subprocess
+    data = _native.library_path().read_bytes()
+    names = set(re.findall(rb"IRIS_(?:HIFIGAN|B16|S3|MRF)_[A-Z0-9_]+", data))
+    assert names == set(), f"environment switch names in the release library: {sorted(names)}"
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(_native.library_path())], capture_output=True, text=True)
+    if syms.returncode == 0:
+        assert not re.search(r"\bgetenv\b", syms.stdout), "the release library imports getenv"
+    # the sources name their switches only through the gated macro
+    for path in (REPO / "iris-tts_amd" / "csrc").glob("*"):
+        if path.suffix in (".h", ".hip") and path.name != "diag_env.h":
+            assert "getenv" not in path.read_text(), path
+
+
+def test_receptive_field_from_config():
+    """streaming.receptive_field_frames: exact interval propagation through the layers; 13 frames for V1
+    (+-12.64 frames probed on the reference), larger for wider kernels / dilations."""
+    from iris.streaming import RECEPTIVE_FIELD_FRAMES, StreamingVocoder, receptive_field_frames
+    assert receptive_field_frames(GeneratorConfig()) == RECEPTIVE_FIELD_FRAMES == 13
+    wide = GeneratorConfig(resblock_kernel_sizes=(3, 7, 13), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 9)))
+    assert receptive_field_frames(wide) > 13
+    small = GeneratorConfig(in_channels=20, upsample_rates=(4, 2, 3), upsample_kernel_sizes=(8, 4, 9),
+                            upsample_initial_channel=48, resblock_kernel_sizes=(3, 5), resblock_dilation_sizes=((1, 2), (2, 6)))
+    need = receptive_field_frames(small)
+    assert need >= 1
+    sv = StreamingVocoder(lambda m: m, config=small)                      # hop and halo come from the configuration
+    assert sv.hop_length == 24 and sv.halo_frames == need
+    with pytest.raises(ValueError):
+        StreamingVocoder(lambda m: m, config=wide, halo_frames=13)        # V1's halo is too small for the wide config
+    with pytest.raises(ValueError):
+        StreamingVocoder(lambda m: m, config=small, hop_length=256)
+
+
+def test_receptive_field_is_tight_on_the_oracle():
+    """For a non-V1 configuration: chunking with the computed halo reproduces the one-shot oracle output, and one
+    frame less visibly does not (so the computed value is the minimum, not merely sufficient)."""
+    from conftest import oracle_config
+    from iris.streaming import StreamingVocoder, plan_chunks, receptive_field_frames
+    from oracle import hifigan_oracle as orc
+    cfg = GeneratorConfig(in_channels=6, upsample_rates=(2, 2), upsample_kernel_sizes=(4, 4), upsample_initial_channel=8,
+                          resblock_kernel_sizes=(3, 5), resblock_dilation_sizes=((1, 2), (1, 3)))
+    sd = seeded_state_dict(cfg, seed=4, gain=1.3, post_gain=3.0)
+    folded, ocfg = orc.to_torch_folded(sd), oracle_config(cfg)
+    fwd = lambda m: orc.generator_forward_torch(folded, np.ascontiguousarray(m), ocfg).numpy()[:, 0, :]
+    need = receptive_field_frames(cfg)
+    mel = seeded_mel(3, 1, 90, n_mels=6)
+    full = fwd(mel)
+    ok = StreamingVocoder(fwd, chunk_frames=16, config=cfg).infer(mel)
+    assert np.abs(ok - full).max() <= 2e-7
+    hop = cfg.hop_length
+    short = np.concatenate([fwd(mel[:, :, c.win_start:c.win_stop])[:, c.emit_slice(hop)]
+                            for c in plan_chunks(90, 16, need - 1)], axis=1)
+    assert np.abs(short - full).max() > 1e-6     # the outermost taps carry little weight, but they are not nothing
+
+
+def test_model_repacks_after_in_place_parameter_edits(monkeypatch):
+    """HiFiGANModel notices in-place edits of its parameters (tensor version counters) and drops the packed engine;
+    invalidate() does it on request.  (A stand-in engine: no GPU in this test.)"""
+    from iris import hifigan_pretrained as hp
+    built = []
+
+    class FakeEngine:
+        def __init__(self, cfg, sd, device):
+            built.append(float(sd["conv_pre.bias"][0]))
+            self.device = device
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(hp, "GeneratorEngine", FakeEngine)
+    monkeypatch.setattr(hp, "require_gpu", lambda: torch.device("cpu"))
+    m = hp.HiFiGANModel(upsample_initial_channel=32)
+    e1 = m.engine()
+    assert m.engine() is e1 and len(built) == 1                      # nothing changed: same engine
+    with torch.no_grad():
+        m.conv_pre.bias.fill_(0.25)                                   # tracked in-place edit: noticed by itself
+    e2 = m.engine()
+    assert e2 is not e1 and built[-1] == 0.25
+    m.conv_pre.bias.data.fill_(0.5)                                   # `.data` bypasses the version counter by design ...
+    assert m.engine() is e2
+    m.invalidate()                                                    # ... so such edits are announced explicitly
+    assert m.engine() is not e2 and built[-1] == 0.5 and len(built) == 3

@@ -51,4 +51,13 @@ def test_pipeline_on_gpu_equals_separate_stages(dtype, exact):
     got = torch.cat(chunks, dim=1)
     assert torch.isfinite(got).all()
     assert torch.equal(got, one_shot) if exact else torch.allclose(got, one_shot, atol=1e-5)
+    if dtype == "f32":
+        # not only self-consistent: against the CPU restatements (PostNet oracle -> generator oracle), one shot.
+        # (PostNet is Keras-only in the reference: its oracle is "parity unpinned", tests/test_postnet.py.)
+        from oracle import hifigan_oracle as orc
+        from oracle import postnet_oracle as porc
+        sd = seeded_state_dict(cfg, seed=11, gain=1.1, post_gain=10.0)
+        refined = porc.postnet_forward_np(post.weights, mel, 3)
+        want = orc.generator_forward_torch(orc.to_torch_folded(sd), refined).numpy()[:, 0, :]
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4
     eng.close()

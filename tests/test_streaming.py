@@ -59,6 +59,10 @@ def test_streaming_engine_equals_one_shot_gpu():
     chunked = torch.cat(parts, dim=1)
     # same fmaf chains per output element whatever the tile origin: seams are exact to rounding
     assert (chunked - full).abs().max().item() <= 1e-6
+    # ... and not merely self-consistent: item 1 of the chunked output against the CPU oracle's one-shot waveform
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel[1:2].cpu().numpy()).numpy()[0, 0]
+    assert np.abs(chunked[1].cpu().numpy() - want).max() <= 1e-4
     eng.close()
 
 
@@ -94,6 +98,9 @@ def test_grouped_streaming_on_gpu_is_exact():
     eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0), dev)
     mel = torch.from_numpy(seeded_mel(9, 1, 1400, log_mel=True)).to(dev)
     one_shot = eng.forward(mel).clone()
-    grouped = StreamingVocoder(eng.forward, group_chunks=4).infer(mel)
+    grouped = StreamingVocoder(eng.forward, group_chunks=4, config=cfg).infer(mel)
     assert torch.equal(grouped, one_shot)
+    sd = seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0)
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel.cpu().numpy()).numpy()[0, 0]
+    assert np.abs(grouped[0].cpu().numpy() - want).max() <= 1e-4
     eng.close()

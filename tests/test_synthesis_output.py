@@ -86,7 +86,17 @@ def test_default_entry_on_gpu(tmp_path, monkeypatch):
     torch.save({k: torch.from_numpy(v) for k, v in seeded_state_dict(seed=2025, gain=1.18, post_gain=20.0).items()}, ck)
     monkeypatch.setattr(hp, "default_checkpoint_path", lambda: ck)
     monkeypatch.setattr(hp, "_vocoder_instance", None)
-    audio = so.vocode_to_wav(seeded_mel(5, 1, 40, log_mel=True), tmp_path / "a.wav")
+    mel = seeded_mel(5, 1, 40, log_mel=True)
+    audio = so.vocode_to_wav(mel, tmp_path / "a.wav")
     assert audio.shape == (40 * 256,) and np.isfinite(audio).all() and np.abs(audio).max() <= 1.0
     with wave.open(str(tmp_path / "a.wav"), "rb") as w:
         assert w.getnframes() == 40 * 256 and w.getframerate() == 22050
+        pcm = np.frombuffer(w.readframes(40 * 256), dtype="<i2")
+    # the waveform against the CPU oracle, and the WAV's PCM samples against the oracle's waveform put through the
+    # stage's own 16-bit rule (clip to [-1, 1], scale by 32767, round).  soundfile -- what the reference calls,
+    # scripts/synthesize.py:212 -- is not importable here: its exact PCM rounding is "parity unpinned"; one LSB covers it.
+    from oracle import hifigan_oracle as orc
+    sd = seeded_state_dict(seed=2025, gain=1.18, post_gain=20.0)
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel).numpy()[0, 0]
+    assert np.abs(audio - want).max() <= 1e-4
+    assert np.abs(pcm.astype(np.int32) - np.rint(np.clip(want, -1, 1) * 32767.0).astype(np.int32)).max() <= 4   # 1e-4 * 32767 = 3.3 LSB

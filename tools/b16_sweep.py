@@ -6,6 +6,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the switches exist only in the diagnostic build (make -C iris-tts_amd/csrc diag); the release library reads none
+os.environ.setdefault("IRIS_HIFIGAN_LIB", os.path.join(ROOT, "iris-tts_amd", "csrc", "libiris_hifigan_diag.so"))
 shape = os.environ.get("SWEEP_SHAPE", "32x500").split("x")
 for spec in sys.argv[1:]:
     env = dict(os.environ)
@@ -14,7 +16,7 @@ for spec in sys.argv[1:]:
             k, v = kv.split("=")
             env[k] = v
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "bf16", "--batch", shape[0], "--frames", shape[1],
-                          "--no-cpu-baseline", "--steps", "10", "--warmup", "2"], env=env, capture_output=True, text=True)
+                          "--no-cpu-baseline --no-extras", "--steps", "10", "--warmup", "2"], env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception:

@@ -5,12 +5,12 @@ set -e
 REPO=$PWD; TAG=${1:-rXX}
 export TMPDIR=/tmp
 python bench.py > gpurun_out/${TAG}_bench.json
-python bench.py --dtype bf16 --batch 32 --frames 500 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16_c3.json
-python bench.py --batch 32 --frames 500 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_f32_c3.json
-python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16_c2.json
+python bench.py --dtype bf16 --batch 32 --frames 500 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_bf16_c3.json
+python bench.py --batch 32 --frames 500 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_f32_c3.json
+python bench.py --dtype bf16 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_bf16_c2.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/${TAG}_prof_f32 --output-format csv -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/${TAG}_bench_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_prof_f32.log
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/${TAG}_prof_bf16 --output-format csv -- python3 $REPO/bench.py --dtype bf16 --batch 32 --frames 500 --steps 10 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/${TAG}_bench_bf16_c3_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_prof_bf16.log
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/${TAG}_prof_f32 --output-format csv -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/${TAG}_bench_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_prof_f32.log
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/${TAG}_prof_bf16 --output-format csv -- python3 $REPO/bench.py --dtype bf16 --batch 32 --frames 500 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $REPO/gpurun_out/${TAG}_bench_bf16_c3_under_rocprof.json 2> $REPO/gpurun_out/${TAG}_prof_bf16.log
 cd $REPO
 cp $(find gpurun_out/${TAG}_prof_f32 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 cp $(find gpurun_out/${TAG}_prof_bf16 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats_bf16_c3.csv
