@@ -203,6 +203,15 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
 int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
                                               void* y_dev, int32_t B, int32_t L, int32_t C_in, int32_t C_out,
                                               int32_t k, int32_t u, int32_t in_act, float slope, void* stream);
+/* One fused ResBlock conv pair of `n_branches` MRF branches in bf16 storage (hifigan_pretrained.py:64-71, one
+ * iteration of the loop):  y_j = Conv1d_{k_j, 1}(LeakyReLU(Conv1d_{k_j, dil_j}(LeakyReLU(x_j)))) + x_j  on bf16
+ * channels-last tensors [B, L, C], C = 32 or 64 (the stages where the bf16 path is HBM-bound); the intermediate never
+ * leaves the CU.  Same rounding points as the two separate bf16 layers (so: bit-identical to them).
+ * Returns IRIS_HIFIGAN_UNSUPPORTED for other channel counts. */
+int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                      const float* const* w2_host, const float* const* b2_host, void* const* y_dev,
+                                      int32_t n_branches, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                      float slope, void* stream);
 /* the ResBlock Conv1d (C -> C, LeakyReLU on the input, optional residual) with fp32 tensors and split-bf16 products
  * (dtype IRIS_HIFIGAN_F32_SPLIT; C % 32 == 0): hifigan_pretrained.py:50-57,64-71. */
 int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,

@@ -6,6 +6,7 @@
 // The MRF mean is formed by the consumer of a stage while it stages its input (SURVEY.md 8d accounting L).
 #include "generator_internal.h"
 #include "conv_mfma_bf16.h"
+#include "mrf_pair_bf16.h"
 #include "conv_mfma_f32s.h"
 #include "conv_post.h"
 
@@ -239,6 +240,41 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         const int nd = h->cfg.num_dilations[0];
         const double n_el = fB * L_out * st.C;
         for (int m = 0; m < nd; ++m) {
+            // C <= 64: conv1 and conv2 of the pair in ONE launch, xt stays in LDS (mrf_pair_bf16.h): two tensor passes
+            // over HBM instead of five.  Algorithmic FLOP / bytes (accounting L) are those of both steps; the record
+            // carries the index of the pair's second step.  (forward_until asking for the state after conv1 gets the
+            // two separate launches for that pair.)
+            {
+                PairLaunch pa; memset(&pa, 0, sizeof(pa));
+                double flops = 0, wbytes = 0;
+                for (int j = 0; j < nk && j < kMaxGroup; ++j) {
+                    const ConvLayer& l1 = st.c1[j][m];
+                    const ConvLayer& l2 = st.c2[j][m];
+                    PairProblem& p = pa.p[j];
+                    p.x = (m == 0) ? ws + w.up : ws + w.y[j];
+                    p.y = ws + w.y[j];
+                    p.w1 = wb + l1.w16_off; p.b1 = blob + l1.b_off;
+                    p.w2 = wb + l2.w16_off; p.b2 = blob + l2.b_off;
+                    p.ks = l1.k; p.dil = l1.dil;
+                    flops += 2.0 * n_el * (l1.C_in * l1.k + l2.C_in * l2.k);
+                    wbytes += 2.0 * (double)(l1.ref_w_floats + l2.ref_w_floats) + 4.0 * (l1.C_out + l2.C_out);
+                }
+                pa.B = B; pa.L = L_out; pa.C = st.C; pa.slope = slope;
+                const bool want_xt = stop.stage == (int)i && stop.step == 2 * m;
+                bool same_k = true;
+                for (int j = 0; j < nk; ++j) same_k = same_k && st.c1[j][m].k == st.c2[j][m].k && st.c2[j][m].dil == 1;
+                if (!want_xt && same_k && pair_applicable(pa, nk)) {
+                    TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
+                    HIP_TRY(launch_pair_bf16(pa, nk, stream));
+                    TRY(prof.end());
+                    if (stop.stage == (int)i && stop.step == 2 * m + 1) {
+                        if (mean_in_y0) *mean_in_y0 = 0;
+                        h->n_rec = prof.idx;
+                        return IRIS_HIFIGAN_OK;
+                    }
+                    continue;
+                }
+            }
             for (int half = 0; half < 2; ++half) {
                 Launch a; init_launch(a);
                 double flops = 0, wbytes = 0;
@@ -338,6 +374,45 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
     a.B = B; a.L_in = L; a.L_out = L; a.C_in = C_in; a.C_out = C_out; a.n_idx = L;
     a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
     HIP_TRY(launch_conv_bf16(a, 1, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                      const float* const* w2_host, const float* const* b2_host, void* const* y_dev,
+                                      int32_t n_branches, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                      float slope, void* stream_) {
+    using namespace iris;
+    using namespace iris::b16;
+    if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || !y_dev || !k || !dil)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (n_branches < 1 || n_branches > kMaxGroup || B < 1 || L < 1 || C < 1 || B > 65535)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_pair shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    PairLaunch a; memset(&a, 0, sizeof(a));
+    DevBytes w1b[kMaxGroup], w2b[kMaxGroup], b1b[kMaxGroup], b2b[kMaxGroup];
+    for (int j = 0; j < n_branches; ++j) {
+        if (!x_dev[j] || !w1_host[j] || !b1_host[j] || !w2_host[j] || !b2_host[j] || !y_dev[j])
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
+        if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad kernel size / dilation");
+        a.p[j].ks = k[j]; a.p[j].dil = dil[j];
+    }
+    a.B = B; a.L = L; a.C = C; a.slope = slope;
+    if (!pair_applicable(a, n_branches))
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "the fused pair kernel takes C = 32 or 64 and windows up to 64 KB");
+    for (int j = 0; j < n_branches; ++j) {
+        std::vector<uint16_t> packed(packed_conv1d_halfs(C, C, k[j]));
+        pack_conv1d_bf16(w1_host[j], C, C, k[j], packed.data());
+        HIP_TRY(w1b[j].upload(packed.data(), packed.size() * sizeof(uint16_t)));
+        pack_conv1d_bf16(w2_host[j], C, C, k[j], packed.data());
+        HIP_TRY(w2b[j].upload(packed.data(), packed.size() * sizeof(uint16_t)));
+        HIP_TRY(b1b[j].upload(b1_host[j], sizeof(float) * C));
+        HIP_TRY(b2b[j].upload(b2_host[j], sizeof(float) * C));
+        a.p[j].x = (const uint16_t*)x_dev[j]; a.p[j].y = (uint16_t*)y_dev[j];
+        a.p[j].w1 = w1b[j].p; a.p[j].w2 = w2b[j].p;
+        a.p[j].b1 = (const float*)b1b[j].p; a.p[j].b2 = (const float*)b2b[j].p;
+    }
+    HIP_TRY(launch_pair_bf16(a, n_branches, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
 }

@@ -121,6 +121,69 @@ def test_bf16_conv_transpose1d_matches_oracle(B, L, Ci, Co, k, u):
 
 
 # ------------------------------------------------------------------------------------------------
+# the fused ResBlock conv pair (mrf_pair_bf16_kernel): conv1 -> LDS -> conv2 + residual in one launch
+# ------------------------------------------------------------------------------------------------
+PAIR_CASES = [
+    # (B, L, C, dils): tile edges of the k = 3 / 7 / 11 branches (T_OUT = M - (k - 1), M = 384 at C = 32, 192 at C = 64),
+    # one-row and shorter-than-halo inputs, several tiles with a ragged tail, a multi-XCD job range
+    (1, 1, 32, (1, 1, 1)), (2, 9, 32, (5, 5, 5)), (1, 373, 32, (3, 3, 3)), (1, 374, 32, (5, 5, 5)), (1, 375, 32, (1, 1, 1)),
+    (2, 1531, 32, (5, 5, 5)), (1, 20000, 32, (3, 3, 3)),
+    (1, 7, 64, (5, 5, 5)), (1, 181, 64, (1, 1, 1)), (1, 182, 64, (3, 3, 3)), (2, 777, 64, (5, 5, 5)), (1, 9000, 64, (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("B,L,C,dils", PAIR_CASES)
+def test_bf16_fused_pair_equals_separate_layers_and_oracle(B, L, C, dils):
+    """y_j = conv2_j(lrelu(conv1_j(lrelu(x_j)))) + x_j for the three branches in ONE launch: bit for bit what the two
+    separate bf16 layers produce (same MFMA order and rounding points; only HBM traffic differs), and within one
+    bf16 ulp of the numpy restatement with those rounding points (hifigan_pretrained.py:64-71)."""
+    from iris import _native
+    lib = _native.load()
+    rng = np.random.default_rng(C + L)
+    ks = (3, 7, 11)
+    xs = [_r16(rng.standard_normal((B, C, L)).astype(np.float32)) for _ in ks]
+    w1 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    w2 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    b1 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    b2 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    xd = [_bf16_cl(x) for x in xs]
+    yd = [torch.full((B, L, C), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in ks]
+    vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
+    _native.check("op_mrf_pair_bf16", lib.iris_hifigan_op_mrf_pair_bf16(
+        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
+        fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]), vp3(*[t.data_ptr() for t in yd]),
+        3, B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None))
+    for j, k in enumerate(ks):
+        xt = torch.full((B, L, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        y2 = torch.full((B, L, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _native.check("op_conv1d_bf16", lib.iris_hifigan_op_conv1d_bf16(
+            xd[j].data_ptr(), _fp(w1[j]), _fp(b1[j]), None, xt.data_ptr(), B, L, C, C, k, dils[j], 1, 0.1, None))
+        _native.check("op_conv1d_bf16", lib.iris_hifigan_op_conv1d_bf16(
+            xt.data_ptr(), _fp(w2[j]), _fp(b2[j]), xd[j].data_ptr(), y2.data_ptr(), B, L, C, C, k, 1, 1, 0.1, None))
+        assert torch.isfinite(yd[j].float()).all(), j
+        assert torch.equal(yd[j], y2), (j, int((yd[j] != y2).sum()))
+        if L <= 2000:     # the fp64 loops of the numpy restatement are slow
+            xt_ref = _r16(orc.conv1d_np(_r16(orc.lrelu_np(xs[j], 0.1)), _r16(w1[j]), b1[j], dils[j]).astype(np.float32))
+            want = orc.conv1d_np(_r16(orc.lrelu_np(xt_ref, 0.1)), _r16(w2[j]), b2[j], 1) + xs[j]
+            got = yd[j].float().cpu().numpy().transpose(0, 2, 1)
+            # (a one-ulp difference in xt propagates: the bound is loose by design, the bit-equality above is the test)
+            assert np.abs(got - want).max() <= 0.05 * max(1.0, np.abs(want).max())
+            assert (np.abs(got - _r16(want.astype(np.float32))) == 0).mean() > 0.9
+
+
+def test_bf16_fused_pair_rejects_other_channel_counts():
+    from iris import _native
+    lib = _native.load()
+    z = torch.zeros((1, 8, 128), dtype=torch.bfloat16, device="cuda")
+    w = np.zeros((128, 128, 3), np.float32)
+    b = np.zeros(128, np.float32)
+    vp1, fp1 = ctypes.c_void_p * 1, ctypes.POINTER(ctypes.c_float) * 1
+    rc = lib.iris_hifigan_op_mrf_pair_bf16(vp1(z.data_ptr()), fp1(_fp(w)), fp1(_fp(b)), fp1(_fp(w)), fp1(_fp(b)), vp1(z.data_ptr()),
+                                           1, 1, 8, 128, (ctypes.c_int32 * 1)(3), (ctypes.c_int32 * 1)(1), 0.1, None)
+    assert rc == 4      # IRIS_HIFIGAN_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------
 # whole generator
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,T,seed,log_mel", [(1, 100, 1001, False), (3, 57, 5, True), (1, 1, 9, False), (5, 2, 10, False),
@@ -170,7 +233,8 @@ def test_bf16_profile_records_cover_algorithmic_work(engine, dev):
     torch.cuda.synchronize()
     recs = eng.read_profile()
     eng.set_profiling(False)
-    assert len(recs) == 30
+    # 1 + 4 * (1 + 6) + 1 layers; the conv pairs of the C = 64 and C = 32 stages run fused (one launch per pair)
+    assert len(recs) == 30 - 2 * 3
     work = algorithmic_work(eng.cfg)
     assert sum(r["flops"] for r in recs) == pytest.approx(work["flop_per_frame"] * B * T, rel=1e-12)
     # accounting L at 2 bytes per element; the mel (read) and the waveform (written) stay fp32; biases stay fp32
