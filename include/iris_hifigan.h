@@ -134,8 +134,14 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
  * workspace at the offsets workspace_layout reports, channels-last [B, L_stage, C_stage]:
  *   pre  conv_pre output [B, T, C0];  up  the stage's ConvTranspose1d output;
  *   y[j] running x of ResBlock j (after an odd step);  xt[j] output of convs1 of ResBlock j (after an even step).
- * *mean_in_y0 (may be NULL) is set to 1 when stop_step is the last step of the stage and the kernel already
- * stored (y[0]+y[1]+y[2])/num_kernels (hifigan_pretrained.py:131-137) in y[0] instead of the branch outputs. */
+ * *flags (may be NULL) receives
+ *   IRIS_HIFIGAN_UNTIL_MEAN_IN_Y0  stop_step is the last step of the stage and the kernel already stored
+ *                                  (y[0]+y[1]+y[2])/num_kernels (hifigan_pretrained.py:131-137) in y[0] instead of the
+ *                                  branch outputs;
+ *   IRIS_HIFIGAN_UNTIL_X_IN_XT     the roles of the y and xt buffers are swapped at this point (the fused conv-pair
+ *                                  kernel of the bf16 path cannot work in place and alternates between them). */
+#define IRIS_HIFIGAN_UNTIL_MEAN_IN_Y0 1
+#define IRIS_HIFIGAN_UNTIL_X_IN_XT 2
 typedef struct iris_hifigan_workspace_map {
     uint64_t pre_offset, up_offset;                 /* byte offsets into the workspace */
     uint64_t y_offset[IRIS_HIFIGAN_MAX_KERNELS];
@@ -148,7 +154,7 @@ int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, i
                                       iris_hifigan_workspace_map* out);
 int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
                                    void* workspace_dev, uint64_t workspace_bytes, int32_t dtype,
-                                   int32_t stop_stage, int32_t stop_step, int32_t* mean_in_y0, void* stream);
+                                   int32_t stop_stage, int32_t stop_step, int32_t* flags, void* stream);
 
 /* Samples of waveform per mel frame (256 for the V1 config). */
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
@@ -205,8 +211,9 @@ int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_
                                               int32_t k, int32_t u, int32_t in_act, float slope, void* stream);
 /* One fused ResBlock conv pair of `n_branches` MRF branches in bf16 storage (hifigan_pretrained.py:64-71, one
  * iteration of the loop):  y_j = Conv1d_{k_j, 1}(LeakyReLU(Conv1d_{k_j, dil_j}(LeakyReLU(x_j)))) + x_j  on bf16
- * channels-last tensors [B, L, C], C = 32 or 64 (the stages where the bf16 path is HBM-bound); the intermediate never
- * leaves the CU.  Same rounding points as the two separate bf16 layers (so: bit-identical to them).
+ * channels-last tensors [B, L, C], C = 32, 64 or 128 (the stages where the bf16 path is HBM-bound or at the ridge); the intermediate never
+ * leaves the CU.  Same rounding points as the two separate bf16 layers (so: bit-identical to them).  NOT in place: no
+ * y_dev[i] may be an x_dev[j] (a block's input window overlaps the rows its neighbours write).
  * Returns IRIS_HIFIGAN_UNSUPPORTED for other channel counts. */
 int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
                                       const float* const* w2_host, const float* const* b2_host, void* const* y_dev,

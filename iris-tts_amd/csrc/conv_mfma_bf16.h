@@ -299,13 +299,19 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     const int ct0 = (tile_co * WC + wc) * NT;        // this wave's first 32-wide C_out tile
     const bool wave_active = ct0 < a.n_ct;           // wave-uniform
 
+    // the accumulators start at the bias (the MFMA's C input): (nt, r) -> channel (ct0+nt)*32 + 8*(r>>2) + 4*hi + (r&3)
     f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int g = 0; g < 4; ++g) {
+            const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + (co < a.C_out ? co : 0));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[m][nt][4 * g + e] = b4[e];
+        }
 
     const unsigned q_bytes = (a.ablate & 16) ? 0u : (unsigned)a.n_ct * 1024u;   // bytes per (tap, 16-channel step)
     const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;                        // (ablation 16: weights from one address)
@@ -361,14 +367,6 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < NP; ++j) resv[m][j] = buf_load4(rr, pvoff[m][j], 0);
-    f32x4 bias4[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = (ct0 + nt) * 32 + 8 * g + 4 * hi;
-            bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + (co < a.C_out ? co : 0));
-        }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -377,7 +375,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e] + bias4[nt][g][e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e];
                 *reinterpret_cast<f32x4*>(scr + lo * RS + (nt * 32 + 8 * g + 4 * hi) * 4) = v;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

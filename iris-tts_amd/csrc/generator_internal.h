@@ -155,7 +155,7 @@ uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T);
 int bf16_workspace_map(const iris_hifigan_handle* h, int B, int T, iris_hifigan_workspace_map* out);
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
                  void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream, const ForwardStop& stop,
-                 int32_t* mean_in_y0);
+                 int32_t* until_flags);
 
 // ---- fp32 storage with split-bf16 products for the ResBlock convs (conv_mfma_f32s.h; iris_hifigan_bf16.hip) ----
 int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob_s3 (null if unsupported)

@@ -306,7 +306,7 @@ int check_forward_args(const iris_hifigan_handle* h, const void* mel_dev, int32_
 // The fp32 / split-product forward.  `stop` (forward_until only): return after MRF step stop.step of stage
 // stop.stage has been queued; *mean_in_y0 then says where that stage's result lies (forward_until's contract).
 int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T, void* wav_dev, void* workspace_dev,
-                uint64_t workspace_bytes, int32_t dtype, hipStream_t stream, const ForwardStop& stop, int32_t* mean_in_y0) {
+                uint64_t workspace_bytes, int32_t dtype, hipStream_t stream, const ForwardStop& stop, int32_t* until_flags) {
     const WsLayout w = ws_layout(h, B, T);
     if (workspace_bytes < w.total * sizeof(float))
         return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
@@ -441,7 +441,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                 }
                 TRY(prof.end());
                 if (stop.stage == (int)i && stop.step == 2 * m + half) {
-                    if (mean_in_y0) *mean_in_y0 = (last_step && prev_summed) ? 1 : 0;
+                    if (until_flags) *until_flags = (last_step && prev_summed) ? IRIS_HIFIGAN_UNTIL_MEAN_IN_Y0 : 0;
                     h->n_rec = prof.idx;
                     return IRIS_HIFIGAN_OK;
                 }
@@ -487,7 +487,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
 
 int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
                                    void* workspace_dev, uint64_t workspace_bytes, int32_t dtype,
-                                   int32_t stop_stage, int32_t stop_step, int32_t* mean_in_y0, void* stream_) {
+                                   int32_t stop_stage, int32_t stop_step, int32_t* flags, void* stream_) {
     TRY(check_forward_args(h, mel_dev, B, T, workspace_dev, dtype));
     if (B == 0 || T == 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "forward_until needs a non-empty input");
     if (stop_stage < 0 || stop_stage >= (int)h->stages.size() || stop_step < 0 || stop_step >= 2 * h->cfg.num_dilations[0])
@@ -496,8 +496,8 @@ int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, 
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
     const ForwardStop stop{stop_stage, stop_step};
     if (dtype == IRIS_HIFIGAN_BF16)
-        return bf16_forward(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream_, stop, mean_in_y0);
-    return forward_f32(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, stop, mean_in_y0);
+        return bf16_forward(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream_, stop, flags);
+    return forward_f32(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, stop, flags);
 }
 
 int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, int32_t T, int32_t dtype,

@@ -177,7 +177,7 @@ int bf16_workspace_map(const iris_hifigan_handle* h, int B, int T, iris_hifigan_
 
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,
                  void* workspace_dev, uint64_t workspace_bytes, hipStream_t stream, const ForwardStop& stop,
-                 int32_t* mean_in_y0) {
+                 int32_t* until_flags) {
     if (!h->blob16)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 path needs channel counts that are multiples of 8 and at most %d MRF kernels", kMaxGroup);
     const Ws16 w = ws16_layout(h, B, T);
@@ -208,6 +208,9 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
     }
 
     int L = T;
+    // where the running x of branch j lives: the fused pair kernel cannot work in place (a block's input window
+    // overlaps its neighbours' output rows), so its output alternates between the y and the xt buffer of the branch
+    const uint16_t* cur[IRIS_HIFIGAN_MAX_KERNELS] = {nullptr};
     for (size_t i = 0; i < h->stages.size(); ++i) {
         const Stage& st = h->stages[i];
         const int L_out = L * st.rate;
@@ -223,7 +226,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
             if (i == 0) { a.p[0].x = ws + w.pre; a.in_act = IN_ACT_LRELU; }
             else {
                 a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk;
-                for (int j = 0; j < nk; ++j) a.xmrf[j] = ws + w.y[j];
+                for (int j = 0; j < nk; ++j) a.xmrf[j] = cur[j];
                 a.p[0].x = a.xmrf[0];
             }
             a.B = B; a.L_in = L; a.L_out = L_out; a.C_in = l.C_in; a.C_out = l.C_out;
@@ -239,6 +242,11 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----
         const int nd = h->cfg.num_dilations[0];
         const double n_el = fB * L_out * st.C;
+        for (int j = 0; j < nk; ++j) cur[j] = ws + w.up;
+        auto report_stop = [&]() {
+            if (until_flags) *until_flags = (cur[0] == ws + w.xt[0]) ? IRIS_HIFIGAN_UNTIL_X_IN_XT : 0;
+            h->n_rec = prof.idx;
+        };
         for (int m = 0; m < nd; ++m) {
             // C <= 64: conv1 and conv2 of the pair in ONE launch, xt stays in LDS (mrf_pair_bf16.h): two tensor passes
             // over HBM instead of five.  Algorithmic FLOP / bytes (accounting L) are those of both steps; the record
@@ -251,8 +259,8 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                     const ConvLayer& l1 = st.c1[j][m];
                     const ConvLayer& l2 = st.c2[j][m];
                     PairProblem& p = pa.p[j];
-                    p.x = (m == 0) ? ws + w.up : ws + w.y[j];
-                    p.y = ws + w.y[j];
+                    p.x = cur[j];
+                    p.y = (cur[j] == ws + w.y[j]) ? ws + w.xt[j] : ws + w.y[j];
                     p.w1 = wb + l1.w16_off; p.b1 = blob + l1.b_off;
                     p.w2 = wb + l2.w16_off; p.b2 = blob + l2.b_off;
                     p.ks = l1.k; p.dil = l1.dil;
@@ -267,11 +275,8 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                     TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
                     HIP_TRY(launch_pair_bf16(pa, nk, stream));
                     TRY(prof.end());
-                    if (stop.stage == (int)i && stop.step == 2 * m + 1) {
-                        if (mean_in_y0) *mean_in_y0 = 0;
-                        h->n_rec = prof.idx;
-                        return IRIS_HIFIGAN_OK;
-                    }
+                    for (int j = 0; j < nk; ++j) cur[j] = pa.p[j].y;
+                    if (stop.stage == (int)i && stop.step == 2 * m + 1) { report_stop(); return IRIS_HIFIGAN_OK; }
                     continue;
                 }
             }
@@ -281,9 +286,12 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 for (int j = 0; j < nk; ++j) {
                     const ConvLayer& l = half == 0 ? st.c1[j][m] : st.c2[j][m];
                     Problem& p = a.p[j];
-                    const uint16_t* cur = (m == 0) ? ws + w.up : ws + w.y[j];  // x entering this pair
-                    if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
-                    else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
+                    // x entering this pair is cur[j]; conv1 writes the branch's other buffer, conv2 (own rows only:
+                    // in place is safe) writes back to cur[j], or to y[j] when cur[j] is the shared upsample output
+                    uint16_t* tmp = (cur[j] == ws + w.xt[j]) ? ws + w.y[j] : ws + w.xt[j];
+                    uint16_t* dst = (cur[j] == ws + w.up) ? ws + w.y[j] : const_cast<uint16_t*>(cur[j]);
+                    if (half == 0) { p.x = cur[j]; p.res = nullptr; p.y = tmp; }
+                    else           { p.x = tmp; p.res = cur[j]; p.y = dst; }
                     p.wp = wb + l.w16_off; p.bias = blob + l.b_off;
                     p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
                     flops += 2.0 * n_el * l.C_in * l.k;
@@ -294,9 +302,10 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops, 2.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
                 HIP_TRY(launch_conv_bf16(a, nk, stream));
                 TRY(prof.end());
+                if (half == 1) for (int j = 0; j < nk; ++j) cur[j] = a.p[j].y;
                 if (stop.stage == (int)i && stop.step == 2 * m + half) {
-                    if (mean_in_y0) *mean_in_y0 = 0;
-                    h->n_rec = prof.idx;
+                    // after conv1 the flag says where xt is NOT: x is still in cur[], xt in the other buffer
+                    report_stop();
                     return IRIS_HIFIGAN_OK;
                 }
             }
@@ -313,14 +322,14 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         if (C == 8 || C == 16 || C == 32 || C == 64) {
             // 16-byte staging, batch folded into the grid (conv_post.h); same arithmetic as the kernel below
             post::ConvPostLaunch a; memset(&a, 0, sizeof(a));
-            for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+            for (int j = 0; j < nk; ++j) a.x[j] = cur[j];
             a.n_in = nk; a.inv_n = 1.0f / (float)nk;
             a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
             a.B = B; a.L = L; a.C = C; a.k = l.k; a.slope = slope;
             HIP_TRY(post::launch_conv_post_t<true>(a, stream));
         } else {
             PostLaunch a; memset(&a, 0, sizeof(a));
-            for (int j = 0; j < nk; ++j) a.x[j] = ws + w.y[j];
+            for (int j = 0; j < nk; ++j) a.x[j] = cur[j];
             a.n_in = nk; a.inv_n = 1.0f / (float)nk;
             a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
             a.B = B; a.L = L; a.C = C; a.k = l.k; a.slope = slope;
@@ -399,7 +408,7 @@ int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* con
     }
     a.B = B; a.L = L; a.C = C; a.slope = slope;
     if (!pair_applicable(a, n_branches))
-        return fail(IRIS_HIFIGAN_UNSUPPORTED, "the fused pair kernel takes C = 32 or 64 and windows up to 64 KB");
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "the fused pair kernel takes C = 32, 64 or 128 and windows up to 64 KB");
     for (int j = 0; j < n_branches; ++j) {
         std::vector<uint16_t> packed(packed_conv1d_halfs(C, C, k[j]));
         pack_conv1d_bf16(w1_host[j], C, C, k[j], packed.data());

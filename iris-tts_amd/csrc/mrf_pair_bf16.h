@@ -27,6 +27,7 @@
 // read the same x); jobs are dealt to the XCDs in contiguous ranges (blockIdx.x % 8 = XCD), so the halo rows that
 // neighbouring tiles share and the windows that sibling branches share are re-read from that XCD's L2.
 #pragma once
+#include <stdio.h>
 #include "conv_mfma_bf16.h"
 
 namespace iris {
@@ -52,38 +53,66 @@ struct PairLaunch {
     int n_jobs;           // tiles x branches (tiles = ceil(L / smallest T_OUT))
     int jobs_per_xcd;     // ceil(n_jobs / 8)
     int ablate;           // diagnostics only: 1 no staging loads, 2 no MFMA loops, 4 no stores, 8 no residual loads
+    int stagger;          // diagnostics only: first-generation blocks start (slot / 256 % 4) * stagger * 64 cycles late
+    unsigned long long* dbg;  // diagnostics only (stamp builds): per-segment cycle sums, else nullptr
 };
 
-// Rows [in_row0, in_row0 + R) x all CIC channels of bf16(LeakyReLU(x)) -> LDS (row stride 2*CIC + 16 bytes).
-template <int CIC>
-__device__ __forceinline__ void pair_stage_rows(const uint16_t* x_item, unsigned tensor_bytes, int L, char* lds,
-                                                int in_row0, int R, float slope, bool skip_loads) {
+constexpr int kPairSpanMax = 50;   // (k-1)*d of the widest supported conv1: k = 11, d = 5
+
+// LeakyReLU for 0 <= slope <= 1 (pair_applicable checks it): max(v, slope*v), two VALU ops instead of three
+__device__ __forceinline__ float lrelu_max(float v, float slope) { return fmaxf(v, v * slope); }
+
+// Weight-fragment ring of the MFMA loop (see mma_chunk in conv_mfma_bf16.h), split so that the first D groups can be
+// requested long before the loop starts: vmcnt retires in order, so requests issued ahead of a phase's HBM loads (or
+// ahead of a barrier) have landed by the time the loop wants them.
+template <int NT, int CIC, int D>
+__device__ __forceinline__ void ring_request(u32x4 (&wv)[D][NT], __amdgpu_buffer_rsrc_t wr, unsigned wvoff,
+                                             unsigned q_bytes, unsigned tap_bytes) {
+    constexpr int QPC = CIC / 16;
+    constexpr int QL = QPC == 8 ? 3 : (QPC == 4 ? 2 : (QPC == 2 ? 1 : 0));
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, (unsigned)(i >> QL) * tap_bytes + (unsigned)(i & (QPC - 1)) * q_bytes);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int MT, int NT, int CIC, int D>
+__device__ __forceinline__ void ring_mma_loop(f32x16 (&acc)[MT][NT], u32x4 (&wv)[D][NT], const char* a_lane, int dil_bytes,
+                                              __amdgpu_buffer_rsrc_t wr, unsigned wvoff, unsigned q_bytes,
+                                              unsigned tap_bytes, int ks) {
+    constexpr int QPC = CIC / 16;
+    constexpr int QL = QPC == 8 ? 3 : (QPC == 4 ? 2 : (QPC == 2 ? 1 : 0));
     constexpr int SB = CIC * 2 + 16;
-    constexpr int PPR = CIC / 8;          // 16-byte pieces per row (power of two)
-    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(x_item, tensor_bytes);
-    const int total = R * PPR;
-    constexpr int U = 4;
-    for (int base = 0; base < total; base += 256 * U) {
-        u32x4 v[U];
-        int ldso[U];
+    const int NG = ks * QPC;
+    auto w_soff = [&](int n) -> unsigned { return (unsigned)(n >> QL) * tap_bytes + (unsigned)(n & (QPC - 1)) * q_bytes; };
+    auto load_a = [&](u32x4 (&av)[MT], int n) {
+        int tap = n >> QL;
+        tap = tap < ks ? tap : ks - 1;
+        const char* ap = a_lane + tap * dil_bytes + (n & (QPC - 1)) * 32;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * 256 + (int)threadIdx.x;
-            const int r = idx / PPR, pc = idx & (PPR - 1);
-            const int row = in_row0 + r;
-            const bool ok = idx < total && row >= 0 && row < L && !skip_loads;
-            v[u] = buf_load4(r0, ok ? (unsigned)(row * CIC + 8 * pc) * 2u : kOob, 0);
-            ldso[u] = idx < total ? r * SB + pc * 16 : -1;
-        }
+        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const u32x4*>(ap + m * 32 * SB);
+    };
+    u32x4 av[2][MT];
+    load_a(av[0], 0);
+    for (int n0 = 0; n0 < NG; n0 += D) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            u32x4 o;
+        for (int i = 0; i < D; ++i) {
+            const int n = n0 + i;
+            load_a(av[(i + 1) & 1], n + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned w = v[u][e];
-                o[e] = pack_bf2(lrelu1(bf_lo(w), slope), lrelu1(bf_hi(w), slope));
-            }
-            if (ldso[u] >= 0) *reinterpret_cast<u32x4*>(lds + ldso[u]) = o;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, wv[i][nt]), __builtin_bit_cast(bf16x8, av[i & 1][m]), acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(n + D));   // past the last tap: out of range, zeros
         }
     }
 }
@@ -95,13 +124,37 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
     static_assert(WT * WC == 4 && WC * NT * 32 == C, "a block owns all C channels");
     constexpr int SB = C * 2 + 16;
     constexpr int M = WT * MT * 32;
+    constexpr int PPR = C / 8;                                           // 16-byte pieces per window row
+    constexpr int NQ = ((M + kPairSpanMax) * PPR + 255) / 256;          // staged pieces per thread: ALL in flight at once
+    constexpr int D = 4;                                                 // weight ring depth (groups)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wt = wave / WC, wc = wave - wt * WC;
     const int lo = lane & 31, hi = lane >> 5;
+#ifdef IRIS_PAIR_STAMPS
+    // diagnostic build only: per-wave cycle totals of [0] requests + window wait + LDS write, [1] barrier, [2] conv1 loop,
+    // [3] barrier + xt write + barrier, [4] conv2 loop, [5] barrier + epilogue, [6] whole block; [7] waves counted
+    unsigned long long seg_t[8];
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+#define PAIR_STAMP(i) seg_t[i] = stamp()
+#else
+#define PAIR_STAMP(i)
+#endif
+    PAIR_STAMP(0);
+#ifdef IRIS_MRF_DIAG
+    if (a.stagger > 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < 1024u) for (unsigned i = 0; i < ((lin >> 8) & 3u) * (unsigned)a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
 
     // job -> (tile, branch): contiguous job ranges per XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    if (slot >= a.jobs_per_xcd) return;
     const int job = xcd * a.jobs_per_xcd + slot;
     if (job >= a.n_jobs) return;
     const int tile = job / a.nz, zr = job - tile * a.nz;
@@ -125,37 +178,73 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
     const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
     const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
     const char* a_lane = lds + (wt * MT * 32 + lo) * SB + hi * 16;
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + item, tensor_bytes);
+    const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(p.w1, (unsigned)ks * tap_bytes);
+    const __amdgpu_buffer_rsrc_t wr2 = make_rsrc(p.w2, (unsigned)ks * tap_bytes);
 
+    // The accumulators START at the bias (the MFMA's C input): no bias registers to keep, no add in the epilogues.
+    // conv_mfma_bf16_kernel does the same, so fused and separate launches still produce identical bits.
     f32x16 acc[MT][NT];
-    auto zero_acc = [&]() {
+    auto load_bias = [&](f32x4 (&bias4)[NT][4], const float* bptr) {   // (nt, g) -> channels (ct0+nt)*32 + 8g + 4hi + {0..3}
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(bptr + (ct0 + nt) * 32 + 8 * g + 4 * hi);
+    };
+    auto init_acc = [&](const f32x4 (&bias4)[NT][4]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[m][nt][r] = bias4[nt][r >> 2][r & 3];
     };
 
-    // ---- 1. x window ----------------------------------------------------------------------------------
-    pair_stage_rows<C>(p.x + item, tensor_bytes, L, lds, o0 - h2 - h1, M + (ks - 1) * dil, a.slope, (a.ablate & 1) != 0);
-    // bias of conv1 for this lane's channels: (nt, g) -> channels (ct0+nt)*32 + 8g + 4hi + {0..3}
+    // ---- 1. requests, oldest first: bias1, conv1's first weight fragments (L2), then the whole x window (HBM) ----------
     f32x4 bias4[NT][4];
+    load_bias(bias4, p.b1);
+    u32x4 wv[D][NT];
+    ring_request<NT, C, D>(wv, wr1, wvoff, q_bytes, tap_bytes);
+    {
+        const int in_row0 = o0 - h2 - h1, R = M + (ks - 1) * dil, total = R * PPR;
+        u32x4 v[NQ];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int u = 0; u < NQ; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            const int r = idx / PPR, pc = idx & (PPR - 1);
+            const int row = in_row0 + r;
+            const bool ok = idx < total && row >= 0 && row < L && !(a.ablate & 1);
+            v[u] = buf_load4(xr, ok ? (unsigned)(row * C + 8 * pc) * 2u : kOob, 0);
+        }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.b1 + (ct0 + nt) * 32 + 8 * g + 4 * hi);
+        for (int u = 0; u < NQ; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            const int r = idx / PPR, pc = idx & (PPR - 1);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned w = v[u][e];
+                o[e] = pack_bf2(lrelu_max(bf_lo(w), a.slope), lrelu_max(bf_hi(w), a.slope));
+            }
+            if (idx < total) *reinterpret_cast<u32x4*>(lds + r * SB + pc * 16) = o;
+        }
+    }
+    PAIR_STAMP(1);
     __syncthreads();
+    PAIR_STAMP(2);
     // ---- 2. conv1 ---------------------------------------------------------------------------------------
-    zero_acc();
-    if (!(a.ablate & 2))
-        mma_chunk<MT, NT, C>(acc, a_lane, dil * SB, make_rsrc(p.w1, (unsigned)ks * tap_bytes), wvoff, q_bytes, tap_bytes, 0u, ks);
-    __syncthreads();                                   // every wave is done with the x window
-    // ---- 3. xt -> LDS: bf16(LeakyReLU(bf16(acc + bias1))), zero outside [0, L) --------------------------------
+    init_acc(bias4);
+    if (!(a.ablate & 2)) ring_mma_loop<MT, NT, C, D>(acc, wv, a_lane, dil * SB, wr1, wvoff, q_bytes, tap_bytes, ks);
+    ring_request<NT, C, D>(wv, wr2, wvoff, q_bytes, tap_bytes);        // conv2's first fragments travel during steps 3
+    load_bias(bias4, p.b2);
+    PAIR_STAMP(3);
+    __syncthreads();                                                    // every wave is done with the x window
+    // ---- 3. xt -> LDS: bf16(LeakyReLU(bf16(acc))) (acc already holds the bias), zero outside [0, L) --------------------------------
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row_l = (wt * MT + m) * 32 + lo;
         const int row_g = o0 - h2 + row_l;
-        const bool inside = row_g >= 0 && row_g < L;
+        const unsigned keep = (row_g >= 0 && row_g < L) ? 0xffffffffu : 0u;   // (a mask, not a branch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -163,28 +252,16 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
                 u32x2 o;
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
-                    const unsigned t = pack_bf2(acc[m][nt][4 * g + 2 * e2] + bias4[nt][g][2 * e2],
-                                                acc[m][nt][4 * g + 2 * e2 + 1] + bias4[nt][g][2 * e2 + 1]);   // the stored xt
-                    o[e2] = inside ? pack_bf2(lrelu1(bf_lo(t), a.slope), lrelu1(bf_hi(t), a.slope)) : 0u;      // conv2's operand
+                    const unsigned t = pack_bf2(acc[m][nt][4 * g + 2 * e2], acc[m][nt][4 * g + 2 * e2 + 1]);   // the stored xt
+                    o[e2] = pack_bf2(lrelu_max(bf_lo(t), a.slope), lrelu_max(bf_hi(t), a.slope)) & keep;       // conv2's operand
                 }
                 *reinterpret_cast<u32x2*>(lds + row_l * SB + ((ct0 + nt) * 32 + 8 * g + 4 * hi) * 2) = o;
             }
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(p.b2 + (ct0 + nt) * 32 + 8 * g + 4 * hi);
-    __syncthreads();
-    // ---- 4. conv2 (dilation 1; rows M .. M+k-2 of the window hold stale bytes: they only reach outputs >= T_OUT) ----
-    zero_acc();
-    if (!(a.ablate & 2))
-        mma_chunk<MT, NT, C>(acc, a_lane, SB, make_rsrc(p.w2, (unsigned)ks * tap_bytes), wvoff, q_bytes, tap_bytes, 0u, ks);
-    __syncthreads();                                   // the epilogue scratch aliases the window
-    // ---- 5. epilogue: + bias2 + x, one rounding to bf16, coalesced 16-byte stores ----------------------------
+    // epilogue geometry and the residual of the first m-tile: requested now, back long before the epilogue
     constexpr int RS = NT * 32 * 4 + 16;               // scratch row stride (bytes) = 16 * odd
     constexpr int PPRO = NT * 4;                       // 16-byte bf16 pieces per row of this wave's channel span
     constexpr int NP = 2 * NT;                         // pieces per lane and m-tile
-    char* scr = lds + wave * (32 * RS);
     const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + item, tensor_bytes);
     const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.x + item, (a.ablate & 8) ? 0u : tensor_bytes);
     unsigned pvoff[MT][NP];
@@ -202,20 +279,34 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
             pvoff[m][j] = (im < T_OUT && o < L) ? (unsigned)(o * C + co) * 2u : kOob;
         }
     }
-    u32x4 resv[MT][NP];
+    u32x4 resv[2][NP];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) resv[m][j] = buf_load4(rr, pvoff[m][j], 0);
+    for (int j = 0; j < NP; ++j) resv[0][j] = buf_load4(rr, pvoff[0][j], 0);
+    __syncthreads();
+    PAIR_STAMP(4);
+    // ---- 4. conv2 (dilation 1; rows M .. M+k-2 of the window hold stale bytes: they only reach outputs >= T_OUT) ----
+    init_acc(bias4);
+    if (!(a.ablate & 2)) ring_mma_loop<MT, NT, C, D>(acc, wv, a_lane, SB, wr2, wvoff, q_bytes, tap_bytes, ks);
+    PAIR_STAMP(5);
+    __syncthreads();                                   // the epilogue scratch aliases the window
+    // ---- 5. epilogue: + x, one rounding to bf16.  Each wave turns its 32-row m-tiles through a private LDS scratch so that
+    // residual loads and stores are 16 bytes per lane and whole 64-byte (NT = 1) / 128-byte row segments per 4 / 8 lanes.
+    // (Measured against an LDS-free epilogue that builds 16-byte pieces with v_permlane32_swap: its stores are 32-byte
+    // segments per row, and it lost 3.5 % at C = 128 and 7 % at C = 64 -- profiles/r02_notes.md.)
+    char* scr = lds + wave * (32 * RS);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+        if (m + 1 < MT) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) resv[(m + 1) & 1][j] = buf_load4(rr, pvoff[m + 1][j], 0);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e] + bias4[nt][g][e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e];
                 *reinterpret_cast<f32x4*>(scr + lo * RS + (nt * 32 + 8 * g + 4 * hi) * 4) = v;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -226,7 +317,7 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
         for (int j = 0; j < NP; ++j) {
             const f32x4 lo4 = *reinterpret_cast<const f32x4*>(scr + pscr[j]);
             const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + pscr[j] + 16);
-            const u32x4 rv = resv[m][j];
+            const u32x4 rv = resv[m & 1][j];
             outp[j][0] = pack_bf2(lo4[0] + bf_lo(rv[0]), lo4[1] + bf_hi(rv[0]));
             outp[j][1] = pack_bf2(lo4[2] + bf_lo(rv[1]), lo4[3] + bf_hi(rv[1]));
             outp[j][2] = pack_bf2(hi4[0] + bf_lo(rv[2]), hi4[1] + bf_hi(rv[2]));
@@ -237,12 +328,20 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
         for (int j = 0; j < NP; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pvoff[m][j]), 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // (store data stays live until every store of the group has issued: see mrf_conv_mfma_f32.h)
 #pragma unroll
         for (int j = 0; j < NP; ++j) asm volatile("" :: "v"(outp[j]));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef IRIS_PAIR_STAMPS
+    PAIR_STAMP(6);
+    if (lane == 0 && a.dbg) {
+        for (int i = 0; i < 6; ++i) atomicAdd(a.dbg + i, seg_t[i + 1] - seg_t[i]);
+        atomicAdd(a.dbg + 6, seg_t[6] - seg_t[0]);
+        atomicAdd(a.dbg + 7, 1ull);
+    }
+#endif
+#undef PAIR_STAMP
 }
 
 // ---- launch ----------------------------------------------------------------------------------------
@@ -256,6 +355,7 @@ inline bool pair_tile_for(int C, PairTile* t) {
         *t = PairTile{2, 2, 3, 1, 4, 192};
         return true;
     }
+    if (C == 128 && IRIS_DIAG_ENV("IRIS_B16_PAIR128", 1)) { *t = PairTile{2, 2, 2, 2, 3, 128}; return true; }
     return false;
 }
 
@@ -263,11 +363,13 @@ inline bool pair_tile_for(int C, PairTile* t) {
 inline bool pair_applicable(const PairLaunch& a, int nz) {
     PairTile t;
     if (nz < 1 || nz > kMaxGroup || !pair_tile_for(a.C, &t)) return false;
+    if (!(a.slope >= 0.f && a.slope <= 1.f)) return false;                        // LeakyReLU is evaluated as max(v, slope*v)
     if ((double)a.L * a.C * 2.0 >= 2147483648.0) return false;
     for (int j = 0; j < nz; ++j) {
         const int ks = a.p[j].ks, d = a.p[j].dil;
         if (ks < 1 || !(ks & 1) || d < 1) return false;
         if (ks - 1 >= t.M / 2) return false;                                     // keeps T_OUT >= M / 2
+        if ((ks - 1) * d > kPairSpanMax) return false;                           // the kernel's staging registers are sized for this
         if ((size_t)(t.M + (ks - 1) * d) * (a.C * 2 + 16) > 64 * 1024) return false; // window must leave room for several blocks per CU
     }
     return IRIS_DIAG_ENV("IRIS_B16_PAIR", 1) != 0;
@@ -276,10 +378,33 @@ inline bool pair_applicable(const PairLaunch& a, int nz) {
 inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     PairTile t;
     if (!pair_tile_for(a.C, &t)) return hipErrorInvalidValue;
+    // never in place: a block's input window overlaps the rows its neighbours write
+    for (int j = 0; j < nz; ++j)
+        for (int i = 0; i < nz; ++i)
+            if (a.p[j].x == a.p[i].y) return hipErrorInvalidValue;
     a.nz = nz;
     a.Qp = packed_qsteps(a.C);
     a.n_ct = packed_cotiles(a.C);
     a.ablate = IRIS_DIAG_ENV("IRIS_B16_ABLATE", 0);
+    a.stagger = IRIS_DIAG_ENV("IRIS_B16_STAGGER", 0);
+    a.dbg = nullptr;
+#ifdef IRIS_PAIR_STAMPS
+    static unsigned long long* dbg_dev = nullptr;
+    if (!dbg_dev && hipMalloc(&dbg_dev, 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(dbg_dev, 0, 8 * sizeof(unsigned long long), stream);
+    a.dbg = dbg_dev;
+    struct StampReport {
+        unsigned long long* d; hipStream_t s; int C, L;
+        ~StampReport() {
+            unsigned long long h[8];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            const double n = (double)h[7], tot = (double)h[6];
+            if (n > 0) fprintf(stderr, "[pair stamps] C=%d L=%d waves=%.0f cyc/wave=%.0f | window %.3f bar %.3f conv1 %.3f bar+xt+bar %.3f conv2 %.3f bar+epilogue %.3f\n",
+                               C, L, n, tot / n, h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot);
+        }
+    } report{dbg_dev, stream, a.C, a.L};
+#endif
     int span = 0, kmax = 1;
     for (int j = 0; j < nz; ++j) {
         const int s = (a.p[j].ks - 1) * a.p[j].dil;
@@ -293,7 +418,7 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     a.n_jobs = (int)n_jobs;
     a.jobs_per_xcd = (int)((n_jobs + 7) / 8);
     const size_t window_bytes = (size_t)(t.M + span) * (a.C * 2 + 16);
-    const size_t scratch_bytes = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);
+    const size_t scratch_bytes = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);      // epilogue transpose, aliases the window
     const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
     dim3 grid((unsigned)(a.jobs_per_xcd * 8), (unsigned)a.B, 1u), block(256);
 #define IRIS_PAIR_CASE(WT_, WC_, MT_, NT_, C_, MINB_)                                                        \
@@ -310,6 +435,7 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     IRIS_PAIR_CASE(4, 1, 3, 1, 32, 4)
     IRIS_PAIR_CASE(2, 2, 3, 1, 64, 4)
     IRIS_PAIR_CASE(4, 1, 2, 2, 64, 3)
+    IRIS_PAIR_CASE(2, 2, 2, 2, 128, 3)
 #undef IRIS_PAIR_CASE
     return hipErrorInvalidValue;
 }

@@ -219,11 +219,14 @@ class GeneratorEngine:
             return t.float().cpu().numpy().transpose(0, 2, 1).copy()
 
         nk = self.cfg.num_kernels
+        y_off, xt_off = wmap.y_offset, wmap.xt_offset
+        if folded.value & 2:                      # IRIS_HIFIGAN_UNTIL_X_IN_XT: the buffers' roles are swapped here
+            y_off, xt_off = xt_off, y_off
         return {"pre": view(wmap.pre_offset, frames, self.cfg.upsample_initial_channel),
                 "up": view(wmap.up_offset, length, ch),
-                "y": [view(wmap.y_offset[j], length, ch) for j in range(nk)],
-                "xt": [view(wmap.xt_offset[j], length, ch) for j in range(nk)],
-                "mean_in_y0": bool(folded.value)}
+                "y": [view(y_off[j], length, ch) for j in range(nk)],
+                "xt": [view(xt_off[j], length, ch) for j in range(nk)],
+                "mean_in_y0": bool(folded.value & 1)}
 
     def read_profile(self) -> List[dict]:
         """Per-launch records of every forward since set_profiling(True); the stream must have

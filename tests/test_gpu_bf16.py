@@ -129,6 +129,7 @@ PAIR_CASES = [
     (1, 1, 32, (1, 1, 1)), (2, 9, 32, (5, 5, 5)), (1, 373, 32, (3, 3, 3)), (1, 374, 32, (5, 5, 5)), (1, 375, 32, (1, 1, 1)),
     (2, 1531, 32, (5, 5, 5)), (1, 20000, 32, (3, 3, 3)),
     (1, 7, 64, (5, 5, 5)), (1, 181, 64, (1, 1, 1)), (1, 182, 64, (3, 3, 3)), (2, 777, 64, (5, 5, 5)), (1, 9000, 64, (1, 1, 1)),
+    (1, 3, 128, (1, 1, 1)), (1, 118, 128, (5, 5, 5)), (2, 119, 128, (3, 3, 3)), (1, 1000, 128, (5, 5, 5)), (1, 4100, 128, (1, 1, 1)),
 ]
 
 
@@ -174,12 +175,12 @@ def test_bf16_fused_pair_equals_separate_layers_and_oracle(B, L, C, dils):
 def test_bf16_fused_pair_rejects_other_channel_counts():
     from iris import _native
     lib = _native.load()
-    z = torch.zeros((1, 8, 128), dtype=torch.bfloat16, device="cuda")
-    w = np.zeros((128, 128, 3), np.float32)
-    b = np.zeros(128, np.float32)
+    z = torch.zeros((1, 8, 256), dtype=torch.bfloat16, device="cuda")
+    w = np.zeros((256, 256, 3), np.float32)
+    b = np.zeros(256, np.float32)
     vp1, fp1 = ctypes.c_void_p * 1, ctypes.POINTER(ctypes.c_float) * 1
     rc = lib.iris_hifigan_op_mrf_pair_bf16(vp1(z.data_ptr()), fp1(_fp(w)), fp1(_fp(b)), fp1(_fp(w)), fp1(_fp(b)), vp1(z.data_ptr()),
-                                           1, 1, 8, 128, (ctypes.c_int32 * 1)(3), (ctypes.c_int32 * 1)(1), 0.1, None)
+                                           1, 1, 8, 256, (ctypes.c_int32 * 1)(3), (ctypes.c_int32 * 1)(1), 0.1, None)
     assert rc == 4      # IRIS_HIFIGAN_UNSUPPORTED
 
 
@@ -204,6 +205,45 @@ def test_bf16_generator_close_to_fp32_and_to_restatement(B, T, seed, log_mel, en
     assert np.abs(emu16 - ref32).mean() <= TOL_BF16_MEAN
 
 
+def test_bf16_intermediates_match_restatement(engine, dev):
+    """Stage by stage (iris_hifigan_forward_until): the upsample output and the MRF mean of every stage against the
+    CPU restatement's taps -- the C = 64 / 32 stages run the fused conv-pair kernel, whose output alternates between
+    the branch's two workspace buffers."""
+    from iris._weights import seeded_mel
+    eng, sd = engine
+    cfg = eng.cfg
+    mel_np = seeded_mel(12, 2, 40, log_mel=True)
+    taps = {}
+    orc.generator_forward_bf16(orc.to_torch_folded(sd), mel_np, taps=taps)
+    mel = torch.from_numpy(mel_np).to(dev)
+    last = 2 * len(cfg.resblock_dilation_sizes[0]) - 1
+    inv_n = np.float32(1.0 / cfg.num_kernels)
+    for i in range(cfg.num_upsamples):
+        got = eng.forward_until(mel, i, last, dtype="bf16")
+        assert not got["mean_in_y0"]
+        up = taps[f"ups.{i}"].numpy()
+        # (rounding differences of earlier stages propagate: only the first stage's input is bit-identical on both sides)
+        assert np.abs(got["up"] - up).max() <= 0.03 * np.abs(up).max() and (got["up"] == up).mean() > (0.9 if i == 0 else 0.3), i
+        y = got["y"]
+        mrf = ((y[0] + y[1]) + y[2]) * inv_n
+        want = taps[f"mrf.{i}"].numpy()
+        d = np.abs(mrf - want)
+        assert d.max() <= 0.03 * np.abs(want).max() and d.mean() <= 2e-3 * np.abs(want).max(), (i, d.max(), d.mean())
+    # mid-pair stop: xt of the first pair of the last stage (that pair then runs as two launches)
+    i = cfg.num_upsamples - 1
+    got = eng.forward_until(mel, i, 0, dtype="bf16")
+    x = torch.from_numpy(got["up"])              # the GPU's own stage input: isolates the one conv
+    import torch.nn.functional as F
+    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    folded = orc.to_torch_folded(sd)
+    for j, k in enumerate(cfg.resblock_kernel_sizes):
+        pfx = f"resblocks.{i * cfg.num_kernels + j}.convs1.0"
+        d0 = cfg.resblock_dilation_sizes[j][0]
+        want = r16(F.conv1d(r16(F.leaky_relu(x, 0.1)), r16(folded[pfx + ".weight"]), folded[pfx + ".bias"], dilation=d0,
+                            padding=(k * d0 - d0) // 2)).numpy()
+        assert np.abs(got["xt"][j] - want).max() <= 0.02 * np.abs(want).max() and (got["xt"][j] == want).mean() > 0.9, j
+
+
 def test_bf16_is_deterministic_and_batch_independent(engine, dev):
     from iris._weights import seeded_mel
     eng, _ = engine
@@ -212,6 +252,13 @@ def test_bf16_is_deterministic_and_batch_independent(engine, dev):
     assert torch.equal(eng.forward(mel, dtype="bf16"), full)
     for b in range(4):
         assert torch.equal(eng.forward(mel[b:b + 1].contiguous(), dtype="bf16")[0], full[b])
+    # several tiles per branch in the fused C = 32 / 64 stages (tile = 374 / 182 rows): neighbouring blocks read each
+    # other's halo rows while others write -- repeated runs must agree bit for bit
+    mel = torch.from_numpy(seeded_mel(78, 3, 700, log_mel=True)).to(dev)
+    full = eng.forward(mel, dtype="bf16").clone()
+    for _ in range(3):
+        assert torch.equal(eng.forward(mel, dtype="bf16"), full)
+    assert torch.equal(eng.forward(mel[1:2].contiguous(), dtype="bf16")[0], full[1])
 
 
 def test_bf16_empty_inputs_and_bad_dtype(engine, dev):
@@ -233,8 +280,8 @@ def test_bf16_profile_records_cover_algorithmic_work(engine, dev):
     torch.cuda.synchronize()
     recs = eng.read_profile()
     eng.set_profiling(False)
-    # 1 + 4 * (1 + 6) + 1 layers; the conv pairs of the C = 64 and C = 32 stages run fused (one launch per pair)
-    assert len(recs) == 30 - 2 * 3
+    # 1 + 4 * (1 + 6) + 1 layers; the conv pairs of the C = 128 / 64 / 32 stages run fused (one launch per pair)
+    assert len(recs) == 30 - 3 * 3
     work = algorithmic_work(eng.cfg)
     assert sum(r["flops"] for r in recs) == pytest.approx(work["flop_per_frame"] * B * T, rel=1e-12)
     # accounting L at 2 bytes per element; the mel (read) and the waveform (written) stay fp32; biases stay fp32

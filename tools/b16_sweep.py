@@ -16,7 +16,7 @@ for spec in sys.argv[1:]:
             k, v = kv.split("=")
             env[k] = v
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "bf16", "--batch", shape[0], "--frames", shape[1],
-                          "--no-cpu-baseline --no-extras", "--steps", "10", "--warmup", "2"], env=env, capture_output=True, text=True)
+                          "--no-cpu-baseline", "--no-extras", "--steps", "10", "--warmup", "2"], env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception:
