@@ -4,7 +4,7 @@
 set -e
 REPO=$PWD; TAG=${1:-rXX}
 export TMPDIR=/tmp
-python bench.py > gpurun_out/${TAG}_bench.json
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 python bench.py --dtype bf16 --batch 32 --frames 500 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_bf16_c3.json
 python bench.py --batch 32 --frames 500 --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_f32_c3.json
 python bench.py --dtype bf16 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_bf16_c2.json
@@ -15,5 +15,5 @@ cd $REPO
 cp $(find gpurun_out/${TAG}_prof_f32 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 cp $(find gpurun_out/${TAG}_prof_bf16 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats_bf16_c3.csv
 tools/hbm_traffic.sh ${TAG}
-tools/hbm_traffic.sh ${TAG}_bf16_c3 --dtype bf16 --batch 32 --frames 500
+PLAN=PUMMMMMMUMMMUMMMUMMMO tools/hbm_traffic.sh ${TAG}_bf16_c3 --dtype bf16 --batch 32 --frames 500
 ls gpurun_out/${TAG}_*.json gpurun_out/${TAG}_*.csv

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """HBM traffic per dispatch of the last forward from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
-usage: tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [launches_per_forward=30]
+usage: tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [plan]
+plan = one letter per launch of a forward: P conv_pre, U upsample, M MRF launch, O conv_post.  Default: the fp32 path
+(P + 4 x (U + 6 M) + O = 30 launches); the bf16 path with fused conv pairs at C <= 128 is PUMMMMMMUMMMUMMMUMMMO (21).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2*FETCH_SIZE*1024;
 WRITE_SIZE*1024 is exact."""
 import collections, csv, json, sys
@@ -12,12 +14,12 @@ def load(path, counter):
             d[int(r["Dispatch_Id"])] = (r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"]))
     return list(d.values())
 
-n = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+plan = sys.argv[4] if len(sys.argv) > 4 else "P" + ("U" + "M" * 6) * 4 + "O"
+n = len(plan)
 fetch, write = load(sys.argv[1], "FETCH_SIZE")[-n:], load(sys.argv[2], "WRITE_SIZE")[-n:]
 assert len(fetch) == len(write) == n, (len(fetch), len(write))
 rows, mrf = [], []
-# launch plan of one forward (iris_hifigan.hip): conv_pre, 4 x (upsample, 6 MRF steps), conv_post
-mrf_pos = {i for i in range(n) if n == 30 and 1 <= i <= 28 and (i - 1) % 7 != 0}
+mrf_pos = {i for i, c in enumerate(plan) if c == "M"}
 for pos, ((kn, grid, f), (kn2, _, w)) in enumerate(zip(fetch, write)):
     assert kn == kn2
     name = kn.split("(")[0].replace("void iris::", "").replace("b16::", "b16::")
