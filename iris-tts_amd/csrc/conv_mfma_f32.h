@@ -54,6 +54,7 @@ struct ConvProblem {
     int dil;            // dilation (rows between taps)
     int pad_left;       // input row of tap 0 for output row-index i is  i - pad_left
     int reserved;
+    const f32x4* wp16;  // the same weights packed for the small-problem kernel (pack_conv1d_weights16), or nullptr
 };
 
 struct ConvLaunch {
@@ -379,6 +380,26 @@ inline void pack_conv1d_weights(const float* w, int C_in, int C_out, int ks, flo
                         float v = 0.f;
                         if (co < C_out && ci < C_in) v = w[((size_t)co * C_in + ci) * ks + kap];
                         out[((((size_t)kap * Gp + g) * n_ct + ct) * 64 + lane) * 4 + e] = v;
+                    }
+}
+
+// The same weights in the fragment order of v_mfma_f32_16x16x4_f32 as the small-problem kernel issues it
+// (mrf_small_f32.h): C_in, C_out multiples of 16.
+//   packed16[((kap*(C_in/16) + gp)*(C_out/16) + ct16)*64 + lane] (an f32x4)
+//       = W[co = 16 ct16 + (lane & 15)][ci = 16 gp + {0, 2, 8, 10}[e] + {0, 4, 1, 5}[lane >> 4]][kap]     e = 0..3
+// i.e. the four A operands of the four MFMAs that cover 16 input channels, for K-quarter kq = lane >> 4.
+inline size_t packed16_conv1d_floats(int C_in, int C_out, int ks) { return (size_t)ks * C_in * C_out; }
+inline void pack_conv1d_weights16(const float* w, int C_in, int C_out, int ks, float* out) {
+    static const int kq_ch[4] = {0, 4, 1, 5}, e_ch[4] = {0, 2, 8, 10};
+    const int ngp = C_in / 16, nct = C_out / 16;
+    for (int kap = 0; kap < ks; ++kap)
+        for (int gp = 0; gp < ngp; ++gp)
+            for (int ct = 0; ct < nct; ++ct)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = 16 * ct + (lane & 15);
+                        const int ci = 16 * gp + e_ch[e] + kq_ch[lane >> 4];
+                        out[((((size_t)kap * ngp + gp) * nct + ct) * 64 + lane) * 4 + e] = w[((size_t)co * C_in + ci) * ks + kap];
                     }
 }
 

@@ -58,6 +58,7 @@ struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on th
     size_t ref_w_floats = 0;                          // size in the reference layout
     size_t w16_off = 0, w16_halfs = 0;                // bf16 path: offset/size (bf16 elements) in blob16
     size_t ws3_off = 0;                               // split path: offset (bf16 elements) of the hi plane in blob_s3
+    size_t w16f_off = (size_t)-1;                     // small-problem kernel: float offset of the 16x16x4 packing in blob_w16, or -1
 };
 
 struct Stage {
@@ -80,6 +81,7 @@ struct iris_hifigan_handle {
     uint16_t* blob16 = nullptr;  // device: packed bf16 weights (biases stay fp32 in `blob`)
     size_t blob16_halfs = 0;
     uint16_t* blob_s3 = nullptr; // device: hi/mid bf16 planes of the ResBlock conv weights (split-product mode), or null
+    float* blob_w16 = nullptr;   // device: ResBlock conv weights in v_mfma_f32_16x16x4_f32 fragment order (small-problem kernel), or null
     int hop = 1;
     int device = 0;
     // profiling

@@ -25,6 +25,7 @@
 #include "generator_internal.h"
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
+#include "mrf_small_f32.h"
 #include "conv_post.h"
 #include "postnet.h"
 
@@ -223,6 +224,29 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
                     "weight upload failed: %s", hipGetErrorString(e));
     }
     if (hipMalloc(&h->tile_counters, kTileCounterWords * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
+    {
+        // second packing of the ResBlock conv weights for the small-problem kernel (mrf_small_f32.h); optional:
+        // without it short inputs simply take the persistent kernel
+        size_t off16 = 0;
+        for (auto& st : h->stages)
+            for (size_t j = 0; j < st.c1.size(); ++j)
+                for (int half = 0; half < 2; ++half)
+                    for (auto& l : (half == 0 ? st.c1[j] : st.c2[j]))
+                        if ((l.C_in & 15) == 0 && (l.C_out & 15) == 0) { l.w16f_off = off16; off16 += packed16_conv1d_floats(l.C_in, l.C_out, l.k); }
+        if (off16 > 0) {
+            std::vector<float> host16(off16);
+            const float* src16 = weights_host;
+            for_each_layer(h, [&](ConvLayer& l) {
+                if (l.w16f_off != (size_t)-1) pack_conv1d_weights16(src16, l.C_in, l.C_out, l.k, host16.data() + l.w16f_off);
+                src16 += l.ref_w_floats + l.C_out;
+            });
+            if (hipMalloc(&h->blob_w16, off16 * sizeof(float)) != hipSuccess ||
+                hipMemcpy(h->blob_w16, host16.data(), off16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                if (h->blob_w16) (void)hipFree(h->blob_w16);
+                h->blob_w16 = nullptr;
+            }
+        }
+    }
     int rc16 = bf16_build_blob(h, weights_host);
     if (rc16 == IRIS_HIFIGAN_OK) rc16 = f32s_build_blob(h, weights_host);
     if (rc16 != IRIS_HIFIGAN_OK) {
@@ -239,6 +263,7 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     if (h->blob) (void)hipFree(h->blob);
     if (h->blob16) (void)hipFree(h->blob16);
     if (h->blob_s3) (void)hipFree(h->blob_s3);
+    if (h->blob_w16) (void)hipFree(h->blob_w16);
     if (h->tile_counters) (void)hipFree(h->tile_counters);
     delete h;
     return IRIS_HIFIGAN_OK;
@@ -393,6 +418,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                     if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
                     else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
                     p.wp = (const f32x4*)(blob + l.w_off); p.bias = blob + l.b_off;
+                    p.wp16 = (h->blob_w16 && l.w16f_off != (size_t)-1) ? (const f32x4*)(h->blob_w16 + l.w16f_off) : nullptr;
                     p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
                     flops += 2.0 * n_el * l.C_in * l.k;
                     wbytes += 4.0 * ((double)l.ref_w_floats + l.C_out);
@@ -428,8 +454,9 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                     ConvLaunch b = a;
                     b.p[0] = a.p[2]; b.p[2] = a.p[0];
                     b.sum_y = ws + w.y[0]; b.sum_div = (float)nk;
-                    // (small problems run one branch per block -- mrf_plan's latency mode -- and cannot sum)
-                    if (mrf_kernel_applicable(b, nk) && !mrf_plan(b, true).zpar) {
+                    // (small problems run one branch per block -- mrf_plan's latency modes -- and cannot sum)
+                    const MrfPlan pq = mrf_kernel_applicable(a, nk) ? mrf_plan(a, true) : MrfPlan{};
+                    if (mrf_kernel_applicable(b, nk) && !pq.zpar && !pq.small) {
                         HIP_TRY(launch_mrf_conv(b, nk, stream));
                         launched = true; prev_summed = true;
                     }
@@ -614,14 +641,14 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
                                  float slope, int32_t plan, void* stream_) {
     if (!x_dev || !w_host || !bias_host || !k || !dil || (!y_dev && !mean_dev))
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
-    if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 3) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
+    if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 4) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
     const int nk = 3;
     for (int j = 0; j < nk; ++j) {
         if (!x_dev[j] || !w_host[j] || !bias_host[j] || (!mean_dev && !y_dev[j])) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
         if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad branch kernel size / dilation");
     }
     hipStream_t stream = (hipStream_t)stream_;
-    DevBuf wb[3];
+    DevBuf wb[3], wb16[3];
     size_t boff[3];
     ConvLaunch a; init_launch(a);
     for (int j = 0; j < nk; ++j) {
@@ -630,7 +657,13 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
         boff[j] = packed_conv1d_floats(C, C, k[j]);
         memcpy(packed.data() + boff[j], bias_host[j], sizeof(float) * C);
         HIP_TRY(wb[j].upload(packed));
+        if ((C & 15) == 0) {
+            std::vector<float> p16(packed16_conv1d_floats(C, C, k[j]));
+            pack_conv1d_weights16(w_host[j], C, C, k[j], p16.data());
+            HIP_TRY(wb16[j].upload(p16));
+        }
         ConvProblem& p = a.p[j];
+        p.wp16 = (const f32x4*)wb16[j].p;
         p.x = x_dev[j]; p.res = res_dev ? res_dev[j] : nullptr; p.y = y_dev ? y_dev[j] : nullptr;
         p.wp = (const f32x4*)wb[j].p; p.bias = wb[j].p + boff[j];
         p.ks = k[j]; p.dil = dil[j]; p.pad_left = dil[j] * (k[j] - 1) / 2;
@@ -643,8 +676,9 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
         for (int j = 0; j < nk; ++j) if (!a.p[j].y) a.p[j].y = mean_dev;     // never written; keeps descriptors valid
     }
     if (!mrf_kernel_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the MRF kernel");
-    const int force = plan == 0 ? -1 : plan - 1;
-    if (mean_dev && force == 2) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block mode cannot form the mean");
+    const int force = plan == 0 ? -1 : (plan == 4 ? 4 : plan - 1);
+    if (mean_dev && (force == 2 || force == 4)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block modes cannot form the mean");
+    if (force == 4 && !mrf_small_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the small-problem kernel needs C %% 32 == 0");
     HIP_TRY(launch_mrf_conv(a, nk, stream, force));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;

@@ -465,7 +465,12 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
 }
 
 // How a grouped MRF step is spread over the chip.
-struct MrfPlan { int MT; bool zpar; long long n_tiles; long long grid; int zb1, zb2; };
+struct MrfPlan { int MT; bool zpar; bool small; long long n_tiles; long long grid; int zb1, zb2; };
+
+// the small-problem kernel (mrf_small_f32.h): 16 x 16 jobs on v_mfma_f32_16x16x4_f32, same bits
+inline bool mrf_small_applicable(const ConvLaunch& a, int nz);
+inline double mrf_small_cycles(const ConvLaunch& a, int nz);
+inline hipError_t launch_mrf_small(ConvLaunch& a, int nz, hipStream_t stream);
 
 inline int mrf_cu_count() { return device_cu_count(); }
 
@@ -477,8 +482,11 @@ inline int mrf_cu_count() { return device_cu_count(); }
 // block counts are the ones that minimise that under nb_11 + nb_7 + nb_3 <= slots.  The mode with the smaller
 // estimate is taken (half-height tiles and zpar carry a few per cent overhead): zpar wins when there are few
 // tiles or their number falls between multiples of the slot count (T = 100 ... 400 frames at batch 1).
+// Small problems (a stage step with fewer 32-row tiles than the chip has room for): the 16 x 16-job kernel of
+// mrf_small_f32.h is taken when its estimate (MFMA work spread over all SIMDs, bounded below by its longest chain) is
+// clearly below the best of the modes above.
 // `force` (>= 0: the single-step test entry point, or the diagnostic build's IRIS_HIFIGAN_MRFPLAN) pins the mode:
-// 0 full-height tiles, 1 half-height tiles, 2 half-height + one branch per block, 3 the round-1 rule.
+// 0 full-height tiles, 1 half-height tiles, 2 half-height + one branch per block, 3 the round-1 rule, 4 the small-problem kernel.
 inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
     const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", -1);
@@ -512,15 +520,22 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
         zpar_units = bestM * 1.03 * 1.06;
     }
     MrfPlan pl;
-    pl.MT = 2; pl.zpar = false; pl.zb1 = pl.zb2 = 0;
+    pl.MT = 2; pl.zpar = false; pl.small = false; pl.zb1 = pl.zb2 = 0;
+    const bool small_ok = allow_zpar && mrf_small_applicable(a, 3);
     if (plan_env >= 0 && plan_env <= 2) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar && zpar_units < 1e29; }
     else if (plan_env == 3) {
         if (4 * tiles(2) < 3 * slots) { pl.MT = 1; pl.zpar = allow_zpar && tiles(1) < n_cu && zpar_units < 1e29; }
+    } else if (plan_env == 4) {
+        pl.small = small_ok;
     } else {
         auto serial = [&](int MT) { return (double)((tiles(MT) + slots - 1) / slots) * 21.0 * MT * (MT == 1 ? 1.03 : 1.0); };
         double best = serial(2);
         if (serial(1) < 0.999 * best) { best = serial(1); pl.MT = 1; }
         if (zpar_units < 0.999 * best) { best = zpar_units; pl.MT = 1; pl.zpar = true; }
+        // one unit = one tap of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles
+        if (small_ok && mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0 && IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSMALL", 1)) {
+            pl.small = true; pl.zpar = false; pl.MT = 1;
+        }
     }
     pl.n_tiles = tiles(pl.MT);
     if (pl.zpar) {
@@ -545,6 +560,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     a.nz = 1;
     a.ablate = IRIS_DIAG_ENV("IRIS_HIFIGAN_ABLATE", 0);
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
+    if (pl.small) return launch_mrf_small(a, nz, stream);
     const int T_BLK = t.WT * pl.MT * 32;
     const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;   // + next-tile word
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)

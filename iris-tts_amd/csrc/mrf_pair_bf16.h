@@ -3,7 +3,7 @@
 // Reference semantics: one iteration of ResBlock.forward's loop (src/iris/hifigan_pretrained.py:64-71)
 //     xt = Conv1d_{k, dil d}(LeakyReLU(x));  y = Conv1d_{k, dil 1}(LeakyReLU(xt)) + x
 // for the branches k = 3 / 7 / 11 of a stage (hifigan_pretrained.py:130-136), with the rounding points of the
-// bf16-storage variant (conv_mfma_bf16.h; oracle/hifigan_oracle.py:generator_forward_bf16): LeakyReLU(x) -> bf16,
+// bf16-storage variant (conv_mfma_bf16.h; its CPU restatement is the test suite's generator_forward_bf16): LeakyReLU(x) -> bf16,
 // xt = bf16(acc + bias), LeakyReLU(xt) -> bf16, y = bf16(acc + bias + x).  The numbers are bit for bit those of the
 // two separate launches of conv_mfma_bf16_kernel (same MFMA order, same roundings) -- what changes is the traffic:
 // xt never leaves the CU.  Unfused, a pair costs five tensor passes over HBM (conv1: read x, write xt; conv2: read

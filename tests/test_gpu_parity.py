@@ -166,12 +166,13 @@ def _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean):
     return status, ([t.cpu().numpy().transpose(0, 2, 1) for t in yd] if not mean else md.cpu().numpy().transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize("plan", [0, 1, 2, 3])
+@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("B,L,C,dils,use_res", MRF_STEP_CASES)
 def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
     """One conv step of the three ResBlock branches (k = 3/7/11; hifigan_pretrained.py:64-71) through the persistent
-    MRF kernel, in the library's own plan (0), with full-height tiles (1), half-height tiles (2) and one branch per
-    block (3), against the numpy oracle's conv1d_np.  All plans run the same fmaf chains: they must agree bit for bit."""
+    MRF kernel, in the library's own plan (0), with full-height tiles (1), half-height tiles (2), one branch per
+    block (3) and through the small-problem kernel (4: 16 x 16 jobs on v_mfma_f32_16x16x4_f32), against the numpy
+    oracle's conv1d_np.  All plans run the same fmaf chains: they must agree bit for bit."""
     rng = np.random.default_rng(C * 7 + L + plan)
     ks = (3, 7, 11)
     xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
