@@ -396,6 +396,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
 #pragma unroll
         for (int j = 0; j < NP; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pvoff[m][j]), 0, 0);
+        asm volatile("s_nop 1");       // explicit wait states behind the dwordx4 stores (see mrf_conv_mfma_f32.h)
         __builtin_amdgcn_sched_barrier(0);
         // the store data must stay live until every store of the group has issued (see the store-data note in
         // mrf_conv_mfma_f32.h: hipcc otherwise re-uses a store's data VGPRs right behind it)

@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_f32s_kernel(const Launch 
             for (int j = 0; j < NP; ++j)
                 __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pv[j]), (int)msoff, 0);
         }
+        asm volatile("s_nop 1");       // explicit wait states behind the dwordx4 stores (see mrf_conv_mfma_f32.h)
         __builtin_amdgcn_sched_barrier(0);
         // store data stays live until every store of the group has issued (store-data note in mrf_conv_mfma_f32.h)
 #pragma unroll

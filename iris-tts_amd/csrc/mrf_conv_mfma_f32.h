@@ -340,6 +340,10 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                     for (int idx = 0; idx < MT * 4; ++idx)
                         if (!(ablate & 4) || outv[idx].x == 1.2345e-30f)
                             buf_store4(outv[idx], yo, t.ovoff4, (unsigned)((idx / 4) * 32 * C + 8 * (idx % 4)) * 4u);
+                    // explicit wait states behind the store group as well: LLVM's store-data hazard handling skips MUBUF
+                    // stores wider than 64 bits whose soffset is an SGPR -- exactly this form (checked in the ISA: the data
+                    // registers of the group are next written only by the following branch, see the keep-alive below)
+                    asm volatile("s_nop 1");
                     stored = true;
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
 #pragma unroll
         for (int j = 0; j < NP; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(outp[j], yr, (int)((a.ablate & 4) ? kOob : pvoff[m][j]), 0, 0);
+        asm volatile("s_nop 1");       // explicit wait states behind the dwordx4 stores (see mrf_conv_mfma_f32.h)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NP; ++j) asm volatile("" :: "v"(outp[j]));
