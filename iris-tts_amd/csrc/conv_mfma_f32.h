@@ -130,6 +130,30 @@ __device__ __forceinline__ void stage_input(const ConvLaunch& a, const ConvProbl
     } else {
         // scalar path: channels-first input (the mel, hifigan_pretrained.py:228) or C_in % 4 != 0
         const int total = R * CIC;
+        if (a.x_channels_first && a.in_act != IN_ACT_MRF_LRELU) {
+            // the mel: eight loads in flight per thread instead of one (conv_pre is latency-bound: 16-64 blocks)
+            constexpr int U = 8;
+            for (int base = tid; base < total; base += 256 * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    const int c = idx / R, r = idx - c * R;         // lanes run along time
+                    const int row = in_row0 + r, ci = c0 + c;
+                    const bool ok = idx < total && row >= 0 && row < L_in && ci < C_in;
+                    v[u] = ok ? p.x[((size_t)b * C_in + ci) * L_in + row] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total) {
+                        const int c = idx / R, r = idx - c * R;
+                        lds[r * S + c] = a.in_act == IN_ACT_LRELU ? lrelu1(v[u], a.slope) : v[u];
+                    }
+                }
+            }
+            return;
+        }
         for (int idx = tid; idx < total; idx += 256) {
             int r, c;
             if (a.x_channels_first) { c = idx / R; r = idx - c * R; }   // lanes run along time
