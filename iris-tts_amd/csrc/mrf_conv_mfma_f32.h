@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #ifdef IRIS_MRF_STAMPS
     // diagnostic build only: per-wave cycle totals of [0] MFMA loops, [1] epilogues, [2] barrier before
     // the LDS write, [3] LDS write, [4] barrier after it, [5] everything (kernel entry to exit)
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [6] ring copy + bias/residual adds, [7] SUM + stores (parts of [1])
     auto stamp = [&]() -> unsigned long long {
         unsigned long long t;
         __builtin_amdgcn_sched_barrier(0);
@@ -309,6 +309,10 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[m][4 * g + e] = (acc[m][4 * g + e] + bias4[g][e]) + resv[m * 4 + g][e];
+#ifdef IRIS_MRF_STAMPS
+                const unsigned long long ts1b = stamp();
+                seg[6] += ts1b - ts1;
+#endif
                 if constexpr (SUM) {
                     // Last conv step of the stage: the block has all branch outputs of its tile, so the MRF
                     // sum and the division by num_kernels (hifigan_pretrained.py:131-137) happen here, in
@@ -350,6 +354,9 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             }
             IRIS_STAMP(ts2);
             IRIS_SEG(1, ts1, ts2);
+#ifdef IRIS_MRF_STAMPS
+            if (last) seg[7] += ts2 - ts1;
+#endif
             if (has_next) {
                 __syncthreads();          // every wave is done reading this chunk's window
                 IRIS_STAMP(ts3);
@@ -443,6 +450,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     if (lane == 0 && a.dbg) {
         for (int i = 0; i < 6; ++i) atomicAdd(a.dbg + i, seg[i]);
         atomicAdd(a.dbg + 6, 1ull);
+        atomicAdd(a.dbg + 8, seg[6]); atomicAdd(a.dbg + 9, seg[7]);
     }
 #endif
 }
@@ -596,8 +604,8 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     } while (0)
 #ifdef IRIS_MRF_STAMPS
     static unsigned long long* dbg_dev = nullptr;
-    if (!dbg_dev) { if (hipMalloc(&dbg_dev, 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
-    (void)hipMemsetAsync(dbg_dev, 0, 8 * sizeof(unsigned long long), stream);
+    if (!dbg_dev) { if (hipMalloc(&dbg_dev, 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
+    (void)hipMemsetAsync(dbg_dev, 0, 16 * sizeof(unsigned long long), stream);
     a.dbg = dbg_dev;
 #endif
     if (t.WT == 4)          IRIS_MRF_LAUNCH_DB(4, 1, 32);     // C <= 32 (mrf_kernel_applicable: CIC == 32 there)
@@ -605,7 +613,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     else                    IRIS_MRF_LAUNCH_DB(1, 4, 64);
 #ifdef IRIS_MRF_STAMPS
     {   // diagnostic build: synchronous read-back of the per-wave cycle shares
-        unsigned long long h[8];
+        unsigned long long h[16];
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
         const double tot = (double)h[5], nw = (double)h[6];
@@ -615,6 +623,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         fprintf(stderr, "[stamps] C=%d L=%d grid=%lld waves=%.0f cyc/wave=%.0f ideal_mfma=%.0f (%.3f) | mfma_loop %.3f epilogue %.3f bar1 %.3f ldswrite %.3f bar2 %.3f other %.3f\n",
                 a.C_in, a.L_in, g, nw, tot / nw, mfma_cyc, mfma_cyc / (tot / nw), h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot,
                 1.0 - (h[0] + h[1] + h[2] + h[3] + h[4]) / tot);
+        fprintf(stderr, "[stamps]   of the epilogue: adds (incl. wait for residual) %.3f, whole last-chunk epilogue %.3f\n", h[8] / tot, h[9] / tot);
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB
