@@ -53,7 +53,6 @@ struct PairLaunch {
     int n_jobs;           // tiles x branches (tiles = ceil(L / smallest T_OUT))
     int jobs_per_xcd;     // ceil(n_jobs / 8)
     int ablate;           // diagnostics only: 1 no staging loads, 2 no MFMA loops, 4 no stores, 8 no residual loads
-    int stagger;          // diagnostics only: first-generation blocks start (slot / 256 % 4) * stagger * 64 cycles late
     unsigned long long* dbg;  // diagnostics only (stamp builds): per-segment cycle sums, else nullptr
 };
 
@@ -146,12 +145,6 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
 #define PAIR_STAMP(i)
 #endif
     PAIR_STAMP(0);
-#ifdef IRIS_MRF_DIAG
-    if (a.stagger > 0) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin < 1024u) for (unsigned i = 0; i < ((lin >> 8) & 3u) * (unsigned)a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-#endif
 
     // job -> (tile, branch): contiguous job ranges per XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -387,7 +380,6 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     a.Qp = packed_qsteps(a.C);
     a.n_ct = packed_cotiles(a.C);
     a.ablate = IRIS_DIAG_ENV("IRIS_B16_ABLATE", 0);
-    a.stagger = IRIS_DIAG_ENV("IRIS_B16_STAGGER", 0);
     a.dbg = nullptr;
 #ifdef IRIS_PAIR_STAMPS
     static unsigned long long* dbg_dev = nullptr;
