@@ -545,7 +545,12 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
         if (serial(1) < 0.999 * best) { best = serial(1); pl.MT = 1; }
         if (zpar_units < 0.999 * best) { best = zpar_units; pl.MT = 1; pl.zpar = true; }
         // one unit = one tap of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles
-        if (small_ok && mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0 && IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSMALL", 1)) {
+        // ... or, measured rather than modelled: at C >= 256 the 16 x 16 kernel is still 12 % ahead at 2,256 rows (a 282-frame
+        // streaming window: 82.6 vs 93.8 us per step) although the estimates say otherwise -- the unit model above ignores that
+        // two one-branch blocks share a CU's matrix pipe there.  Not extrapolated beyond what was measured.
+        const bool measured_win = a.C_in >= 256 && (long long)a.L_out * a.B <= 2600;
+        if (small_ok && IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSMALL", 1) &&
+            (measured_win || mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0)) {
             pl.small = true; pl.zpar = false; pl.MT = 1;
         }
     }
