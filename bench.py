@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (no grid / host_inclusive / "
                     "configs2 / configs3_n1 / other_modes sub-records)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--per-launch-events", action="store_true",
+                    help="one HIP-event pair per launch (31 events per forward, ~0.1 ms of stream time) instead of one per "
+                         "layer group (the MRF launches of a stage share a pair: 11 events)")
     ap.add_argument("--graph", action="store_true", help="replay the forward as a hipGraph (no per-launch records: "
                     "roofline is then null; the default eager mode is the measured configuration)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the collective "
@@ -158,7 +161,7 @@ def summarize_records(recs, steps, cfg):
     by_kind, detail = {}, {}
     for r in recs:
         k = by_kind.setdefault(r["kind"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-        k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += 1
+        k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["n"] += r.get("launches", 1)
     for kind, k in by_kind.items():
         detail[kind] = {"launches_per_step": k["n"] // steps, "ms_per_step": k["ms"] / steps,
                         "tflops": k["flops"] / (k["ms"] * 1e-3) / 1e12, "gbs": k["bytes"] / (k["ms"] * 1e-3) / 1e9}
@@ -334,7 +337,7 @@ def rank_main(args):
         return elapsed, recs, mel_np, mel
 
     # ---- the headline: W untimed warm-up steps, exactly K timed steps between barrier + synchronize -------------
-    profile = not args.no_profile and not args.graph and not stub
+    profile = 0 if (args.no_profile or args.graph or stub) else (1 if args.per_launch_events else 2)
     elapsed, recs, mel_np, mel = run_sharded(T, args.steps, args.warmup, profile)
     samples_per_step = G * T * hop
     value = samples_per_step * args.steps / elapsed
@@ -379,7 +382,7 @@ def rank_main(args):
                                 f"waveform shards over {args.backend}"
                                 + (" (RCCL)" if args.backend == "nccl" else " (control-flow rehearsal, not a measurement)"))
                                if world > 1 else "single GPU",
-                   "launch_events_in_timed_region": profile, "hipgraph_replay": bool(args.graph)},
+                   "launch_events_in_timed_region": {0: False, 1: "per launch", 2: "per layer group"}[profile], "hipgraph_replay": bool(args.graph)},
         "rtf": (ms_per_step * 1e-3) / (T * hop / SAMPLE_RATE) if G == 1 else None,
         "flop_per_step": flop_per_frame * G * T,
         "tflops_whole_path": flop_per_frame * G * T / (ms_per_step * 1e-3) / 1e12,
@@ -396,7 +399,7 @@ def rank_main(args):
         g = []
         for frames in (100, 500, 1000):
             m = torch.from_numpy(seeded_mel(1001 if frames == 100 else 1002, 1, frames)).to(dev)
-            ms, r, _ = timed_forward(eng, m, "f32", 20, 5, dev, True, cfg)
+            ms, r, _ = timed_forward(eng, m, "f32", 20, 5, dev, 2, cfg)
             bk, _ = summarize_records(r, 20, cfg)
             rf = roofline_of(bk, "f32", 20, ms, 1, frames)
             g.append({"frames": frames, "batch": 1, "dtype": "f32", "ms": ms, "samples_per_s": frames * hop / (ms * 1e-3),
@@ -419,7 +422,7 @@ def rank_main(args):
         # ---- BASELINE.json configs[2]: batch 32 x 500 frames, bf16 storage ------------------------------------------------
         try:
             m2 = torch.from_numpy(seeded_mel(1003, 32, 500)).to(dev)
-            ms2, r2, _ = timed_forward(eng, m2, "bf16", 10, 3, dev, True, cfg)
+            ms2, r2, _ = timed_forward(eng, m2, "bf16", 10, 3, dev, 2, cfg)
             bk2, det2 = summarize_records(r2, 10, cfg)
             out["configs2"] = {"workload": "batch 32 x 80-mel x 500 frames, bf16 storage / fp32 accumulate (BASELINE.json configs[2])",
                                "dtype": "bf16", "ms_per_step": ms2, "samples_per_s": 32 * 500 * hop / (ms2 * 1e-3), "steps": 10,

@@ -89,8 +89,8 @@ typedef struct iris_hifigan_handle iris_hifigan_handle;
 typedef struct iris_hifigan_launch_record {
     int32_t kind;      /* 0 conv_pre, 1 upsample (ConvTranspose1d), 2 MRF ResBlock conv group, 3 conv_post */
     int32_t stage;     /* upsample stage index, -1 for conv_pre / conv_post */
-    int32_t step;      /* 0..2*num_dilations-1 inside a stage's MRF, else 0 */
-    int32_t reserved;
+    int32_t step;      /* 0..2*num_dilations-1 inside a stage's MRF, else 0 (grouped record: that of its first launch) */
+    int32_t launches;  /* kernel launches this record covers: 1, or in grouped mode the MRF launches of a stage */
     double flops;      /* algorithmic FLOP of this launch (2*MAC, zero padding counted)   */
     double bytes;      /* algorithmic bytes of this launch, accounting L of SURVEY.md 8d  */
     float ms;          /* hipEventElapsedTime of this launch on the forward's stream      */
@@ -159,7 +159,9 @@ int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, 
 /* Samples of waveform per mel frame (256 for the V1 config). */
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
 
-/* Profiling: when enabled every launch of forward is bracketed by hipEvents on `stream`.
+/* Profiling: enabled = 1 brackets every launch of forward by hipEvents on `stream`; enabled = 2 does the same but
+ * gives the MRF launches of a stage ONE record (flops/bytes summed, `launches` counted): 11 events per forward
+ * instead of 31 -- an event costs about 3 us of stream time, which is 10 % of a 100-frame forward.
  * Records accumulate over successive forwards until set_profiling is called again (which resets
  * them).  After the stream has been synchronised, read_profile copies up to `capacity` records and
  * returns how many launches were recorded. */

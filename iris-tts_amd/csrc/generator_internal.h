@@ -85,7 +85,7 @@ struct iris_hifigan_handle {
     int hop = 1;
     int device = 0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;          // 0 off, 1 one record per launch, 2 the MRF launches of a stage share one record
     std::vector<hipEvent_t> ev;          // event pool, n_ev in use
     size_t n_ev = 0;
     std::vector<iris_hifigan_launch_record> recs;
@@ -117,6 +117,7 @@ struct Prof {
     hipStream_t stream;
     int idx = 0;        // next record
     bool open = false;  // a start event for the next launch is already on the stream
+    bool pending = false;  // grouped mode: record idx covers the MRF launches of a stage so far and has no end event yet
     int mark(hipEvent_t* out) {
         if (h->n_ev >= h->ev.size()) {
             const size_t old = h->ev.size();
@@ -127,26 +128,52 @@ struct Prof {
         HIP_TRY(hipEventRecord(*out, stream));
         return IRIS_HIFIGAN_OK;
     }
+    // grouped mode (set_profiling(h, 2)): the MRF launches of a stage share ONE record (flops and bytes summed,
+    // `launches` counted), so a forward carries 11 events instead of 31 -- an event costs ~3 us of stream time
+    int close_group() {
+        if (!pending) return IRIS_HIFIGAN_OK;
+        int rc = mark(&h->rec_ev[idx].second);
+        if (rc != IRIS_HIFIGAN_OK) return rc;
+        pending = false;
+        open = true;
+        ++idx;
+        return IRIS_HIFIGAN_OK;
+    }
     int begin(int kind, int stage, int step, double flops, double bytes) {
         if (!h->profiling) return IRIS_HIFIGAN_OK;
+        const bool grouped = h->profiling == 2 && kind == 2;
+        if (pending) {
+            iris_hifigan_launch_record& g = h->recs[idx];
+            if (grouped && g.stage == stage) { g.flops += flops; g.bytes += bytes; g.launches += 1; return IRIS_HIFIGAN_OK; }
+            int rc = close_group();
+            if (rc != IRIS_HIFIGAN_OK) return rc;
+        }
         if ((size_t)idx >= h->recs.size()) { h->recs.resize(idx + 64); h->rec_ev.resize(idx + 64); }
         iris_hifigan_launch_record& r = h->recs[idx];
         memset(&r, 0, sizeof(r));
-        r.kind = kind; r.stage = stage; r.step = step; r.flops = flops; r.bytes = bytes;
+        r.kind = kind; r.stage = stage; r.step = step; r.launches = 1; r.flops = flops; r.bytes = bytes;
         if (!open) {
             int rc = mark(&h->rec_ev[idx].first);
             if (rc != IRIS_HIFIGAN_OK) return rc;
         } else {
             h->rec_ev[idx].first = h->rec_ev[idx - 1].second;
         }
+        pending = grouped;
         return IRIS_HIFIGAN_OK;
     }
     int end() {
-        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        if (!h->profiling || pending) return IRIS_HIFIGAN_OK;
         int rc = mark(&h->rec_ev[idx].second);
         if (rc != IRIS_HIFIGAN_OK) return rc;
         open = true;
         ++idx;
+        return IRIS_HIFIGAN_OK;
+    }
+    // end of a forward (or of forward_until): closes an open group and publishes the record count
+    int finish() {
+        int rc = close_group();
+        if (rc != IRIS_HIFIGAN_OK) return rc;
+        h->n_rec = idx;
         return IRIS_HIFIGAN_OK;
     }
 };

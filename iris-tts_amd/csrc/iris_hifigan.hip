@@ -288,7 +288,7 @@ int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, in
 
 int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
-    h->profiling = enabled != 0;
+    h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     h->n_rec = 0;
     h->n_ev = 0;
     return IRIS_HIFIGAN_OK;
@@ -469,7 +469,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                 TRY(prof.end());
                 if (stop.stage == (int)i && stop.step == 2 * m + half) {
                     if (until_flags) *until_flags = (last_step && prev_summed) ? IRIS_HIFIGAN_UNTIL_MEAN_IN_Y0 : 0;
-                    h->n_rec = prof.idx;
+                    TRY(prof.finish());
                     return IRIS_HIFIGAN_OK;
                 }
             }
@@ -490,7 +490,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
         HIP_TRY(post::launch_conv_post(a, stream));
         TRY(prof.end());
     }
-    h->n_rec = prof.idx;
+    TRY(prof.finish());
     return IRIS_HIFIGAN_OK;
 }
 

@@ -243,9 +243,9 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         const int nd = h->cfg.num_dilations[0];
         const double n_el = fB * L_out * st.C;
         for (int j = 0; j < nk; ++j) cur[j] = ws + w.up;
-        auto report_stop = [&]() {
+        auto report_stop = [&]() -> int {
             if (until_flags) *until_flags = (cur[0] == ws + w.xt[0]) ? IRIS_HIFIGAN_UNTIL_X_IN_XT : 0;
-            h->n_rec = prof.idx;
+            return prof.finish();
         };
         for (int m = 0; m < nd; ++m) {
             // C <= 64: conv1 and conv2 of the pair in ONE launch, xt stays in LDS (mrf_pair_bf16.h): two tensor passes
@@ -276,7 +276,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                     HIP_TRY(launch_pair_bf16(pa, nk, stream));
                     TRY(prof.end());
                     for (int j = 0; j < nk; ++j) cur[j] = pa.p[j].y;
-                    if (stop.stage == (int)i && stop.step == 2 * m + 1) { report_stop(); return IRIS_HIFIGAN_OK; }
+                    if (stop.stage == (int)i && stop.step == 2 * m + 1) return report_stop();
                     continue;
                 }
             }
@@ -305,8 +305,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 if (half == 1) for (int j = 0; j < nk; ++j) cur[j] = a.p[j].y;
                 if (stop.stage == (int)i && stop.step == 2 * m + half) {
                     // after conv1 the flag says where xt is NOT: x is still in cur[], xt in the other buffer
-                    report_stop();
-                    return IRIS_HIFIGAN_OK;
+                    return report_stop();
                 }
             }
         }
@@ -337,7 +336,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         }
         TRY(prof.end());
     }
-    h->n_rec = prof.idx;
+    TRY(prof.finish());
     return IRIS_HIFIGAN_OK;
 }
 

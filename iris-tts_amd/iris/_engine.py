@@ -69,7 +69,7 @@ class GeneratorEngine:
         self.hop_length = int(hop.value)
         self._workspace: Optional[torch.Tensor] = None
         self._graphs: dict = {}
-        self._profiling = False
+        self._profiling = 0
 
     # -- lifetime ----------------------------------------------------------------------------
     def close(self) -> None:
@@ -171,7 +171,7 @@ class GeneratorEngine:
             entry = (graph, static_in, static_out, ws_ptr)
             self._graphs[key] = entry
             if was_profiling:
-                self.set_profiling(True)
+                self.set_profiling(was_profiling)
         graph, static_in, static_out, ws_ptr = entry
         if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
             # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
@@ -182,9 +182,11 @@ class GeneratorEngine:
         return static_out
 
     # -- profiling (bench.py roofline leg) -----------------------------------------------------
-    def set_profiling(self, enabled: bool) -> None:
+    def set_profiling(self, enabled) -> None:
+        """False/0 off; True/1 one record (two events) per launch; 2 the MRF launches of a stage share one record
+        (11 events per forward instead of 31: an event costs about 3 us of stream time)."""
         _native.check("iris_hifigan_set_profiling", self.lib.iris_hifigan_set_profiling(self._handle, int(enabled)))
-        self._profiling = bool(enabled)
+        self._profiling = int(enabled)
 
     # -- intermediates (parity tests) ------------------------------------------------------------
     def forward_until(self, mel: torch.Tensor, stage: int, step: int, dtype: Optional[str] = None) -> dict:
@@ -242,7 +244,7 @@ class GeneratorEngine:
         for i in range(min(n.value, cap)):
             r = recs[i]
             out.append({"kind": KIND_NAMES.get(r.kind, str(r.kind)), "stage": r.stage, "step": r.step,
-                        "flops": r.flops, "bytes": r.bytes, "ms": r.ms})
+                        "launches": max(int(r.launches), 1), "flops": r.flops, "bytes": r.bytes, "ms": r.ms})
         return out
 
 

@@ -62,7 +62,7 @@ class LaunchRecord(ctypes.Structure):
         ("kind", ctypes.c_int32),
         ("stage", ctypes.c_int32),
         ("step", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("launches", ctypes.c_int32),
         ("flops", ctypes.c_double),
         ("bytes", ctypes.c_double),
         ("ms", ctypes.c_float),
@@ -80,7 +80,7 @@ class WorkspaceMap(ctypes.Structure):
         ("xt_offset", ctypes.c_uint64 * MAX_KERNELS),
         ("total_bytes", ctypes.c_uint64),
         ("element_bytes", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("launches", ctypes.c_int32),
     ]
 
 

@@ -291,6 +291,13 @@ def test_bf16_profile_records_cover_algorithmic_work(engine, dev):
             + 2.0 * (eng.cfg.stage_channels(eng.cfg.num_upsamples - 1) * eng.cfg.post_kernel_size))   # conv_post weights fp32
     assert sum(r["bytes"] for r in recs) == pytest.approx(want, rel=1e-9)
     assert all(r["ms"] > 0 for r in recs)
+    eng.set_profiling(2)                     # grouped: one record per stage's MRF launches (6 separate or 3 fused)
+    eng.forward(torch.from_numpy(seeded_mel(1, B, T)).to(dev), dtype="bf16")
+    torch.cuda.synchronize()
+    grouped = eng.read_profile()
+    eng.set_profiling(False)
+    assert len(grouped) == 10 and [g["launches"] for g in grouped if g["kind"] == "mrf_resblock_conv"] == [6, 3, 3, 3]
+    assert sum(g["bytes"] for g in grouped) == pytest.approx(want, rel=1e-9)
 
 
 def test_bf16_config3_full_size_properties(engine, dev):

@@ -362,7 +362,21 @@ def test_profile_records_cover_algorithmic_work(dev):
     assert sum(r["flops"] for r in recs) == pytest.approx(work["flop_per_frame"] * B * T, rel=1e-12)
     act_bytes = sum(r["bytes"] for r in recs) - 4.0 * work["weight_values"]
     assert act_bytes == pytest.approx(4.0 * work["elements_per_frame"] * B * T, rel=1e-12)
-    assert all(r["ms"] > 0 for r in recs)
+    assert all(r["ms"] > 0 for r in recs) and all(r["launches"] == 1 for r in recs)
+    # grouped records (what bench.py times with): the six MRF launches of a stage share one record -- same work, 11 records
+    eng.set_profiling(2)
+    eng.forward(torch.from_numpy(seeded_mel(1, B, T)).to(dev))
+    eng.forward(torch.from_numpy(seeded_mel(1, B, T)).to(dev))
+    torch.cuda.synchronize()
+    grouped = eng.read_profile()
+    assert len(grouped) == 2 * (1 + 4 * 2 + 1)
+    assert [g["kind"] for g in grouped[:4]] == ["conv_pre", "upsample", "mrf_resblock_conv", "upsample"]
+    assert sum(g["launches"] for g in grouped) == 2 * 30
+    assert all(g["launches"] == 6 for g in grouped if g["kind"] == "mrf_resblock_conv")
+    assert sum(g["flops"] for g in grouped) == pytest.approx(2 * sum(r["flops"] for r in recs), rel=1e-12)
+    assert sum(g["bytes"] for g in grouped) == pytest.approx(2 * sum(r["bytes"] for r in recs), rel=1e-12)
+    assert all(g["ms"] > 0 for g in grouped)
+    eng.set_profiling(False)
     eng.close()
 
 

@@ -8,7 +8,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 cfg = GeneratorConfig(); eng = GeneratorEngine(cfg, seeded_state_dict(cfg), torch.device("cuda", 0))
 mel = torch.from_numpy(seeded_mel(1, B, T)).cuda()
 for _ in range(3): eng.forward(mel)
-torch.cuda.synchronize(); eng.set_profiling(True)
+torch.cuda.synchronize(); eng.set_profiling(1)
 for _ in range(5): eng.forward(mel)
 torch.cuda.synchronize(); recs = eng.read_profile(); n = len(recs) // 5
 for i in range(n):
