@@ -514,7 +514,10 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const long long blocks2 = (long long)((a.n_idx + t.T_BLK - 1) / t.T_BLK) * a.n_co_blk * nz * a.B;
     const int MT = mt_env ? mt_env : (blocks2 < 2LL * n_cu ? 1 : 2);
     const int T_BLK = t.WT * MT * 32;
-    const size_t lds_bytes = (size_t)(T_BLK + span) * (t.CIC + 4) * sizeof(float);
+    // conv_pre of the V1 generator (80 mel bins, channels-first -> 512): one 80-channel chunk instead of 64 + 16.  The launch
+    // has 64-128 blocks, so its time is one block's serial time, and each chunk costs a staging round trip and two barriers.
+    const int CIC = (a.C_in == 80 && a.x_channels_first && t.WT == 1) ? 80 : t.CIC;
+    const size_t lds_bytes = (size_t)(T_BLK + span) * (CIC + 4) * sizeof(float);
     const int n_t = (a.n_idx + T_BLK - 1) / T_BLK;
     a.ablate = IRIS_DIAG_ENV("IRIS_HIFIGAN_ABLATE", 0);
     dim3 grid((unsigned)(n_t * a.n_co_blk * nz), (unsigned)a.B, 1u), block(256);
@@ -533,9 +536,10 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
 #define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
     do { if (MT == 1) IRIS_LAUNCH_K(conv_mfma_f32_kernel<WT_, WC_, 1, CIC_>);                     \
          else         IRIS_LAUNCH_K(conv_mfma_f32_kernel<WT_, WC_, 2, CIC_>); } while (0)
-    if (t.WT == 4 && t.CIC == 32)      IRIS_LAUNCH(4, 1, 32);
+    if (t.WT == 4 && CIC == 32)        IRIS_LAUNCH(4, 1, 32);
     else if (t.WT == 4)                IRIS_LAUNCH(4, 1, 64);
     else if (t.WT == 2)                IRIS_LAUNCH(2, 2, 64);
+    else if (CIC == 80)                IRIS_LAUNCH(1, 4, 80);
     else                               IRIS_LAUNCH(1, 4, 64);
 #undef IRIS_LAUNCH_K
 #undef IRIS_LAUNCH
