@@ -21,7 +21,7 @@
 //      (the last k-1 would need xt rows this block does not have) -- blocks advance by T_OUT rows
 //   5. epilogue as in conv_mfma_bf16.h (per-wave LDS transpose, 16-byte residual loads and stores).
 // The (k-1)/M rows of conv2 that are computed and thrown away are the price of keeping xt on chip: 0.5-2.6 % at
-// M = 384, 1-5 % at M = 192.
+// M = 384, 1-5 % at M = 192-256.
 //
 // Block -> job mapping: job = (tile, branch) with the branch fastest (the branches of the first pair of a stage all
 // read the same x); jobs are dealt to the XCDs in contiguous ranges (blockIdx.x % 8 = XCD), so the halo rows that
@@ -343,13 +343,19 @@ struct PairTile { int WT, WC, MT, NT, MINB, M; };
 
 inline bool pair_tile_for(int C, PairTile* t) {
     const int v64 = IRIS_DIAG_ENV("IRIS_B16_PAIR64", 0);
-    if (C == 32) { *t = PairTile{4, 1, 3, 1, 4, 384}; return true; }
+    if (C == 32) { *t = PairTile{4, 1, 3, 1, 4, 384}; return true; }   // (512 rows at three blocks per CU: no difference)
     if (C == 64) {
+        // 256 rows as 2 x 2 waves of 128 x 32 at three blocks per CU: 2 % ahead of 192 rows at four (2.09 vs 2.13 ms)
         if (v64 == 1) { *t = PairTile{4, 1, 2, 2, 3, 256}; return true; }
-        *t = PairTile{2, 2, 3, 1, 4, 192};
+        if (v64 == 2) { *t = PairTile{2, 2, 3, 1, 4, 192}; return true; }
+        *t = PairTile{2, 2, 4, 1, 3, 256};
         return true;
     }
-    if (C == 128 && IRIS_DIAG_ENV("IRIS_B16_PAIR128", 1)) { *t = PairTile{2, 2, 2, 2, 3, 128}; return true; }
+    // C = 128: 192 rows at two blocks per CU beat 128 rows at three (stage 1 of configs[2]: 3.75 vs 3.95 ms): a weight
+    // fragment (1 KB per wave, from L2) feeds three MFMAs per channel tile instead of two, and 10 of 192 conv2 rows are
+    // thrown away instead of 10 of 128
+    if (C == 128 && IRIS_DIAG_ENV("IRIS_B16_PAIR128", 1) == 2) { *t = PairTile{2, 2, 2, 2, 3, 128}; return true; }
+    if (C == 128 && IRIS_DIAG_ENV("IRIS_B16_PAIR128", 1)) { *t = PairTile{2, 2, 3, 2, 2, 192}; return true; }
     return false;
 }
 
@@ -364,7 +370,7 @@ inline bool pair_applicable(const PairLaunch& a, int nz) {
         if (ks < 1 || !(ks & 1) || d < 1) return false;
         if (ks - 1 >= t.M / 2) return false;                                     // keeps T_OUT >= M / 2
         if ((ks - 1) * d > kPairSpanMax) return false;                           // the kernel's staging registers are sized for this
-        if ((size_t)(t.M + (ks - 1) * d) * (a.C * 2 + 16) > 64 * 1024) return false; // window must leave room for several blocks per CU
+        if ((size_t)(t.M + (ks - 1) * d) * (a.C * 2 + 16) > 66 * 1024) return false; // window must leave room for two blocks per CU
     }
     return IRIS_DIAG_ENV("IRIS_B16_PAIR", 1) != 0;
 }
@@ -428,7 +434,9 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     IRIS_PAIR_CASE(4, 1, 3, 1, 32, 4)
     IRIS_PAIR_CASE(2, 2, 3, 1, 64, 4)
     IRIS_PAIR_CASE(4, 1, 2, 2, 64, 3)
+    IRIS_PAIR_CASE(2, 2, 4, 1, 64, 3)
     IRIS_PAIR_CASE(2, 2, 2, 2, 128, 3)
+    IRIS_PAIR_CASE(2, 2, 3, 2, 128, 2)
 #undef IRIS_PAIR_CASE
     return hipErrorInvalidValue;
 }
