@@ -544,13 +544,12 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
         double best = serial(2);
         if (serial(1) < 0.999 * best) { best = serial(1); pl.MT = 1; }
         if (zpar_units < 0.999 * best) { best = zpar_units; pl.MT = 1; pl.zpar = true; }
-        // one unit = one tap of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles
-        // ... or, measured rather than modelled: at C >= 256 the 16 x 16 kernel is still 12 % ahead at 2,256 rows (a 282-frame
-        // streaming window: 82.6 vs 93.8 us per step) although the estimates say otherwise -- the unit model above ignores that
-        // two one-branch blocks share a CU's matrix pipe there.  Not extrapolated beyond what was measured.
-        const bool measured_win = a.C_in >= 256 && (long long)a.L_out * a.B <= 2600;
+        // one unit = one tap of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles.
+        // (A rule that also took the kernel for the C = 256 stage up to 2,600 rows was tried and removed: it rested on numbers
+        // from the diagnostic build, whose persistent kernel is ~10 % slower; in the release build it won 5 % at 282 frames
+        // and lost 10 % at 200 -- profiles/r02_notes.md.)
         if (small_ok && IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSMALL", 1) &&
-            (measured_win || mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0)) {
+            mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0) {
             pl.small = true; pl.zpar = false; pl.MT = 1;
         }
     }

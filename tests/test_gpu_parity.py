@@ -333,8 +333,8 @@ def test_generator_empty_inputs(dev):
 @pytest.mark.parametrize("B,T", [(4, 40), (12, 40), (2, 282)])
 def test_generator_is_deterministic_and_batch_independent(B, T, dev):
     """Batch items are independent: item b of a batch equals the same mel run alone -- bit for bit, also
-    when the batch and the single item take different kernels (12 x 40 and 2 x 282 frames: the stage-0 MRF steps of the
-    batch run on the persistent kernel, those of an item alone on the 16 x 16-job kernel, mrf_plan's 2,600-row rule)."""
+    when the batch and the single item take different kernels (12 x 40 frames: the stage-0 MRF steps of the batch run on
+    the persistent kernel, those of a 40-frame item alone on the 16 x 16-job kernel; 2 x 282: different launch plans)."""
     from iris._engine import GeneratorEngine
     from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
     cfg = GeneratorConfig()
