@@ -201,6 +201,15 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
                                  int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
                                  float slope, int32_t plan, void* stream);
 
+/* One ResBlock conv PAIR of the three branches in one launch, exact fp32 (csrc/mrf_pair_f32.h; C = 32 or 64,
+ * k[j] in {3, 7, 11}): y_j = Conv1d_{k[j], 1}(LeakyReLU(Conv1d_{k[j], dil[j]}(LeakyReLU(x_j)))) + x_j
+ * (hifigan_pretrained.py:64-71), bit for bit what two iris_hifigan_op_mrf_step calls produce.  y_dev must not
+ * alias x_dev.  Returns IRIS_HIFIGAN_UNSUPPORTED for other shapes. */
+int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                 const float* const* w2_host, const float* const* b2_host, float* const* y_dev,
+                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, void* stream);
+
 /* bf16 variants of the two layers above (dtype IRIS_HIFIGAN_BF16): x_dev / res_dev / y_dev are bf16
  * channels-last [B, L, C] (C_in % 8 == 0, C_out % 4 == 0); host weights are fp32 in the reference layout and are
  * rounded to bf16 (nearest even); bias stays fp32; accumulation is fp32, one rounding to bf16 at the store.

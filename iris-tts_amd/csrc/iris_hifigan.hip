@@ -26,6 +26,7 @@
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
 #include "mrf_small_f32.h"
+#include "mrf_pair_f32.h"
 #include "conv_post.h"
 #include "postnet.h"
 
@@ -407,29 +408,105 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
         // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----
         const int nd = h->cfg.num_dilations[0];
         const double n_el = fB * L_out * st.C;
-        for (int m = 0; m < nd; ++m) {
-            for (int half = 0; half < 2; ++half) {
-                ConvLaunch a; init_launch(a);
-                double flops = 0, wbytes = 0;
-                for (int j = 0; j < nk; ++j) {
-                    const ConvLayer& l = half == 0 ? st.c1[j][m] : st.c2[j][m];
-                    ConvProblem& p = a.p[j];
-                    const float* cur = (m == 0) ? ws + w.up : ws + w.y[j];  // x entering this pair
-                    if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
-                    else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
-                    p.wp = (const f32x4*)(blob + l.w_off); p.bias = blob + l.b_off;
-                    p.wp16 = (h->blob_w16 && l.w16f_off != (size_t)-1) ? (const f32x4*)(h->blob_w16 + l.w16f_off) : nullptr;
-                    p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
-                    flops += 2.0 * n_el * l.C_in * l.k;
-                    wbytes += 4.0 * ((double)l.ref_w_floats + l.C_out);
+        const int use_mrf = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRF", 1);
+        const int use_sum = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSUM", 1);
+        // one conv step (half 0: convs1[m], half 1: convs2[m] + residual) of all branches, separate launches
+        auto fill_step = [&](ConvLaunch& a, int m, int half, double& flops, double& wbytes) {
+            init_launch(a);
+            flops = 0; wbytes = 0;
+            for (int j = 0; j < nk; ++j) {
+                const ConvLayer& l = half == 0 ? st.c1[j][m] : st.c2[j][m];
+                ConvProblem& p = a.p[j];
+                const float* cur = (m == 0) ? ws + w.up : ws + w.y[j];  // x entering this pair
+                if (half == 0) { p.x = cur; p.res = nullptr; p.y = ws + w.xt[j]; }
+                else           { p.x = ws + w.xt[j]; p.res = cur; p.y = ws + w.y[j]; }
+                p.wp = (const f32x4*)(blob + l.w_off); p.bias = blob + l.b_off;
+                p.wp16 = (h->blob_w16 && l.w16f_off != (size_t)-1) ? (const f32x4*)(h->blob_w16 + l.w16f_off) : nullptr;
+                p.ks = l.k; p.dil = l.dil; p.pad_left = l.dil * (l.k - 1) / 2;
+                flops += 2.0 * n_el * l.C_in * l.k;
+                wbytes += 4.0 * ((double)l.ref_w_floats + l.C_out);
+            }
+            a.B = B; a.L_in = L_out; a.L_out = L_out; a.C_in = st.C; a.C_out = st.C;
+            a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
+            a.dyn_counter = dyn_tiles ? h->tile_counters + ((int)i * 2 * nd + 2 * m + half) : nullptr;
+        };
+        // ---- fused conv pairs (mrf_pair_f32.h; C = 32 / 64, exact fp32): conv1 -> xt in LDS -> conv2 + residual in ONE launch,
+        // bit for bit the two separate launches.  A fused pair cannot run in place, so the running x of a branch alternates
+        // between its y and xt buffers, arranged so that the last fused pair leaves it in y (where the separate launches and
+        // the next layer expect it).  Taken for SMALL problems only -- those whose last step would not be the persistent
+        // kernel's summing launch anyway (one-branch-per-block modes) and for which pair_f32_plan measured the fused
+        // kernel ahead; on large problems the persistent kernel's cross-tile prefetch wins.  forward_until asking for a
+        // state after a conv1 gets the separate launches for that stage.
+        auto fill_pair = [&](PairLaunchF32& pa, int m, double& flops, double& wbytes) -> bool {
+            memset(&pa, 0, sizeof(pa));
+            flops = 0; wbytes = 0;
+            bool ok = nk <= kMaxGroup;
+            for (int j = 0; j < nk && ok; ++j) {
+                const ConvLayer& c1 = st.c1[j][m];
+                const ConvLayer& c2 = st.c2[j][m];
+                ok = c1.k == c2.k && c2.dil == 1 && c1.C_in == st.C && c1.C_out == st.C && c2.C_in == st.C && c2.C_out == st.C;
+                PairProblemF32& p = pa.p[j];
+                p.w1 = (const f32x4*)(blob + c1.w_off); p.b1 = blob + c1.b_off;
+                p.w2 = (const f32x4*)(blob + c2.w_off); p.b2 = blob + c2.b_off;
+                p.ks = c1.k; p.dil = c1.dil;
+                flops += 2.0 * n_el * st.C * (c1.k + c2.k);
+                wbytes += 4.0 * ((double)c1.ref_w_floats + c1.C_out + (double)c2.ref_w_floats + c2.C_out);
+            }
+            pa.B = B; pa.L = L_out; pa.C = st.C; pa.slope = slope;
+            return ok;
+        };
+        int n_fused = 0;
+        if (dtype == IRIS_HIFIGAN_F32 && use_mrf && !(stop.stage == (int)i && !(stop.step & 1))) {
+            bool all_ok = true;
+            for (int m = 0; m < nd && all_ok; ++m) {
+                PairLaunchF32 pa; double f, wb;
+                all_ok = fill_pair(pa, m, f, wb) && pair_f32_applicable(pa, nk) && pair_f32_plan(pa, nk).take;
+            }
+            if (all_ok) {
+                bool sums = false;          // (the same decision as at the last step below)
+                if (use_sum && nk == 3) {
+                    ConvLaunch a; double f, wb;
+                    fill_step(a, nd - 1, 1, f, wb);
+                    if (mrf_kernel_applicable(a, nk)) {
+                        const MrfPlan pq = mrf_plan(a, true);
+                        ConvLaunch b = a;
+                        b.p[0] = a.p[2]; b.p[2] = a.p[0];
+                        b.sum_y = ws + w.y[0]; b.sum_div = (float)nk;
+                        sums = mrf_kernel_applicable(b, nk) && !pq.zpar && !pq.small;
+                    }
                 }
-                a.B = B; a.L_in = L_out; a.L_out = L_out; a.C_in = st.C; a.C_out = st.C;
-                a.n_idx = L_out; a.in_act = IN_ACT_LRELU; a.slope = slope;
-                a.dyn_counter = dyn_tiles ? h->tile_counters + ((int)i * 2 * nd + 2 * m + half) : nullptr;
+                // (summing launch in use: at C = 32 the first nd-1 pairs are still ahead fused up to ~100 k rows -- 200 frames:
+                //  174 vs 201 us for the stage's MRF steps; from ~700 frames on the persistent kernel is ahead by 1-4 %)
+                n_fused = !sums ? nd : ((st.C == 32 && (long long)L_out * B <= 100000) ? nd - 1 : 0);
+            }
+        }
+        const float* cur_x[kMaxGroup];
+        for (int j = 0; j < nk && j < kMaxGroup; ++j) cur_x[j] = ws + w.up;
+        for (int m = 0; m < nd; ++m) {
+            if (m < n_fused) {
+                PairLaunchF32 pa; double flops, wbytes;
+                (void)fill_pair(pa, m, flops, wbytes);
+                const bool to_y = ((n_fused - 1 - m) & 1) == 0;
+                for (int j = 0; j < nk; ++j) { pa.p[j].x = cur_x[j]; pa.p[j].y = to_y ? ws + w.y[j] : ws + w.xt[j]; }
+                // algorithmic FLOP / bytes (accounting L) are those of both steps; the record carries the second step's index
+                TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 4.0 * n_el * nk * 5 + wbytes));
+                HIP_TRY(launch_pair_f32(pa, nk, stream));
+                TRY(prof.end());
+                for (int j = 0; j < nk; ++j) cur_x[j] = pa.p[j].y;
+                if (m == nd - 1) prev_summed = false;
+                if (stop.stage == (int)i && stop.step == 2 * m + 1) {
+                    if (until_flags) *until_flags = to_y ? 0 : IRIS_HIFIGAN_UNTIL_X_IN_XT;
+                    TRY(prof.finish());
+                    return IRIS_HIFIGAN_OK;
+                }
+                continue;
+            }
+            for (int half = 0; half < 2; ++half) {
+                ConvLaunch a;
+                double flops = 0, wbytes = 0;
+                fill_step(a, m, half, flops, wbytes);
                 TRY(prof.begin(2, (int)i, 2 * m + half, flops,
                                4.0 * n_el * nk * (half == 0 ? 2 : 3) + wbytes));
-                const int use_mrf = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRF", 1);
-                const int use_sum = IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSUM", 1);
                 const bool last_step = m == nd - 1 && half == 1;
                 bool launched = false;
                 if (dtype == IRIS_HIFIGAN_F32_SPLIT && f32s_step_applicable(h, st.C, L_out, nk)) {
@@ -680,6 +757,41 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
     if (mean_dev && (force == 2 || force == 4)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block modes cannot form the mean");
     if (force == 4 && !mrf_small_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the small-problem kernel needs C %% 32 == 0");
     HIP_TRY(launch_mrf_conv(a, nk, stream, force));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+}
+
+int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                 const float* const* w2_host, const float* const* b2_host, float* const* y_dev,
+                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, void* stream_) {
+    if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || !y_dev || !k || !dil)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_pair shape");
+    const int nk = 3;
+    hipStream_t stream = (hipStream_t)stream_;
+    DevBuf wb[3];
+    PairLaunchF32 pa; memset(&pa, 0, sizeof(pa));
+    for (int j = 0; j < nk; ++j) {
+        if (!x_dev[j] || !w1_host[j] || !b1_host[j] || !w2_host[j] || !b2_host[j] || !y_dev[j])
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
+        if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad branch kernel size / dilation");
+        const size_t wf = packed_conv1d_floats(C, C, k[j]), cpad = ((size_t)C + 3) & ~(size_t)3;
+        std::vector<float> packed(2 * wf + 2 * cpad);
+        pack_conv1d_weights(w1_host[j], C, C, k[j], packed.data());
+        pack_conv1d_weights(w2_host[j], C, C, k[j], packed.data() + wf);
+        memcpy(packed.data() + 2 * wf, b1_host[j], sizeof(float) * C);
+        memcpy(packed.data() + 2 * wf + cpad, b2_host[j], sizeof(float) * C);
+        HIP_TRY(wb[j].upload(packed));
+        PairProblemF32& p = pa.p[j];
+        p.x = x_dev[j]; p.y = y_dev[j];
+        p.w1 = (const f32x4*)wb[j].p; p.w2 = (const f32x4*)(wb[j].p + wf);
+        p.b1 = wb[j].p + 2 * wf; p.b2 = wb[j].p + 2 * wf + cpad;
+        p.ks = k[j]; p.dil = dil[j];
+    }
+    pa.B = B; pa.L = L; pa.C = C; pa.slope = slope;
+    if (!pair_f32_applicable(pa, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the fused fp32 pair kernel");
+    HIP_TRY(launch_pair_f32(pa, nk, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
 }

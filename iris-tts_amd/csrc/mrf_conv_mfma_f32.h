@@ -31,6 +31,10 @@ namespace iris {
 #define IRIS_MRF_ABLATE(a) 0
 #endif
 
+#ifndef IRIS_ZPAR_ONE_PER_CU_DEFAULT
+#define IRIS_ZPAR_ONE_PER_CU_DEFAULT 1   // (A/B builds: 0 = one-branch-per-block mode always spreads over every block slot)
+#endif
+
 #ifndef IRIS_MRF_MINWAVES
 #define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
 #endif
@@ -513,7 +517,7 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     long long nb[3] = {1, 1, 1};
     double zpar_units = 1e30;
     const long long n1 = tiles(1);
-    if (allow_zpar && n1 > 0) {
+    auto split = [&](long long limit, long long (&out)[3]) -> double {
         double bestM = 1e30;
         for (int c = 0; c < 3; ++c)
             for (long long r = 1; r <= 4096; r = r < 64 ? r + 1 : r * 2) {
@@ -527,9 +531,37 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
                     cand[d] = (n1 + rd - 1) / rd;
                     sum += cand[d];
                 }
-                if (ok && sum <= slots) { bestM = (double)M; nb[0] = cand[0]; nb[1] = cand[1]; nb[2] = cand[2]; }
+                if (ok && sum <= limit) { bestM = (double)M; out[0] = cand[0]; out[1] = cand[1]; out[2] = cand[2]; }
             }
+        return bestM;
+    };
+    // Two blocks on a CU share its four matrix pipes: a CU's time is the SUM of the chains of its blocks (block i and, when
+    // the grid has more blocks than CUs, block i + n_cu; blocks are dispatched heaviest branch first).  So a split over
+    // at most n_cu blocks with somewhat longer chains can beat the split that uses every slot (230-330 frames at batch 1,
+    // stage 0: 86 -> 69 us per step).
+    auto cu_units = [&](const long long (&x)[3]) -> double {
+        const long long total = x[0] + x[1] + x[2];
+        auto units = [&](long long idx) -> double {
+            const int c = idx < x[2] ? 2 : (idx < x[2] + x[1] ? 1 : 0);
+            return (double)((n1 + x[c] - 1) / x[c]) * cost[c];
+        };
+        double worst = 0;
+        for (long long i = 0; i < total && i < n_cu; ++i) {
+            const double t = units(i) + (i + n_cu < total ? units(i + n_cu) : 0.0);
+            if (t > worst) worst = t;
+        }
+        return worst;
+    };
+    if (allow_zpar && n1 > 0) {
+        const double bestM = split(slots, nb);
         zpar_units = bestM * 1.03 * 1.06;
+        if (bestM < 1e29 && nb[0] + nb[1] + nb[2] > n_cu && IRIS_DIAG_ENV("IRIS_HIFIGAN_ZPAR_ONE_PER_CU", IRIS_ZPAR_ONE_PER_CU_DEFAULT)) {
+            long long nb1[3] = {1, 1, 1};
+            const double M1 = split(n_cu, nb1);
+            // (0.85: a lone wave per SIMD does not keep its matrix pipe as busy as two that cover each other's waits --
+            //  with the chains level, 600 frames, the one-per-CU split was 5-12 % slower)
+            if (M1 < 1e29 && M1 < 0.85 * cu_units(nb)) { nb[0] = nb1[0]; nb[1] = nb1[1]; nb[2] = nb1[2]; }
+        }
     }
     MrfPlan pl;
     pl.MT = 2; pl.zpar = false; pl.small = false; pl.zb1 = pl.zb2 = 0;

@@ -106,6 +106,8 @@ SYMBOLS = {
     "iris_hifigan_op_conv_post": (_i32, [_vp, _vp, _vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_mrf_step": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_vp), _c.POINTER(_vp), _vp,
                                        _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _i32, _vp]),
+    "iris_hifigan_op_mrf_pair": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
+                                       _c.POINTER(_vp), _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
     "iris_hifigan_op_mrf_pair_bf16": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
                                             _c.POINTER(_vp), _i32, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
     "iris_hifigan_op_conv1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),

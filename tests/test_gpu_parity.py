@@ -214,6 +214,43 @@ def test_mrf_summing_step_matches_oracle(lib, B, L, C, plan):
     assert np.array_equal(got, ((sep[0] + sep[1]) + sep[2]) / np.float32(3))
 
 
+@pytest.mark.parametrize("B,L,C,dils", [(1, 700, 32, (1, 1, 1)), (2, 333, 32, (5, 5, 5)), (1, 520, 64, (3, 3, 3)), (3, 190, 64, (5, 5, 5)),
+                                        (1, 5, 32, (3, 3, 3)), (2, 11000, 64, (3, 3, 3))])   # (the last one: 128-row tiles at C = 64)
+def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils):
+    """The fused fp32 conv pair (csrc/mrf_pair_f32.h: conv1 -> xt in LDS -> conv2 + residual, C = 32 / 64) against the numpy
+    oracle's ResBlock arithmetic (hifigan_pretrained.py:64-71), and bit for bit against the two separate launches of the
+    persistent kernel it replaces -- several tiles per branch, ragged lengths, a length shorter than the kernel."""
+    rng = np.random.default_rng(C * 11 + L)
+    ks = (3, 7, 11)
+    xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    w1 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    b1 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    w2 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    b2 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    xd = [_cl(x) for x in xs]
+    yd = [torch.full((B, L, C), float("nan"), device="cuda") for _ in range(3)]
+    vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
+    _check("op_mrf_pair", lib.iris_hifigan_op_mrf_pair(
+        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
+        fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]), vp3(*[t.data_ptr() for t in yd]),
+        B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None))
+    got = [t.cpu().numpy().transpose(0, 2, 1) for t in yd]
+    _, xt = _mrf_step(lib, xs, w1, b1, None, B, L, C, dils, 0, mean=False)
+    _, sep = _mrf_step(lib, xt, w2, b2, xs, B, L, C, (1, 1, 1), 0, mean=False)
+    for j in range(3):
+        want_xt = orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), w1[j], b1[j], dils[j]).astype(np.float32)
+        want = orc.conv1d_np(orc.lrelu_np(want_xt, 0.1), w2[j], b2[j], 1) + xs[j]
+        assert np.isfinite(got[j]).all()
+        assert np.abs(got[j] - want).max() <= 2 * TOL_LAYER * max(1.0, np.abs(want).max()), j
+        assert np.array_equal(got[j], sep[j]), j
+    # aliased buffers are refused (a block's window overlaps the rows its neighbours write)
+    status = lib.iris_hifigan_op_mrf_pair(
+        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
+        fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]), vp3(*[t.data_ptr() for t in xd]),
+        B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None)
+    assert status != 0
+
+
 def test_mrf_step_rejects_what_the_kernel_cannot_take(lib):
     x = [np.zeros((1, 30, 40), np.float32)] * 3
     w = [np.zeros((30, 30, k), np.float32) for k in (3, 7, 11)]
@@ -359,7 +396,8 @@ def test_profile_records_cover_algorithmic_work(dev):
     eng.forward(torch.from_numpy(seeded_mel(1, B, T)).to(dev))
     torch.cuda.synchronize()
     recs = eng.read_profile()
-    assert len(recs) == 30      # 1 + 4*(1 + 6) + 1 launches per forward
+    # 1 + 4 * (1 + 6) + 1 layers; the C = 64 / 32 stages run their three conv pairs fused (one launch per pair) at this size
+    assert len(recs) == 30 - 2 * 3
     work = algorithmic_work(cfg)
     assert work["flop_per_frame"] == 614_105_088 and work["elements_per_frame"] == 1_305_936
     assert sum(r["flops"] for r in recs) == pytest.approx(work["flop_per_frame"] * B * T, rel=1e-12)
@@ -374,8 +412,8 @@ def test_profile_records_cover_algorithmic_work(dev):
     grouped = eng.read_profile()
     assert len(grouped) == 2 * (1 + 4 * 2 + 1)
     assert [g["kind"] for g in grouped[:4]] == ["conv_pre", "upsample", "mrf_resblock_conv", "upsample"]
-    assert sum(g["launches"] for g in grouped) == 2 * 30
-    assert all(g["launches"] == 6 for g in grouped if g["kind"] == "mrf_resblock_conv")
+    assert sum(g["launches"] for g in grouped) == 2 * 24
+    assert [g["launches"] for g in grouped[:10] if g["kind"] == "mrf_resblock_conv"] == [6, 6, 3, 3]
     assert sum(g["flops"] for g in grouped) == pytest.approx(2 * sum(r["flops"] for r in recs), rel=1e-12)
     assert sum(g["bytes"] for g in grouped) == pytest.approx(2 * sum(r["bytes"] for r in recs), rel=1e-12)
     assert all(g["ms"] > 0 for g in grouped)
