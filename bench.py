@@ -189,8 +189,8 @@ def roofline_of(by_kind, dtype, steps, ms_per_step, batch, frames):
     if dtype in ("f32", "f32s"):
         # f32s: three bf16 MFMAs per fp32 product -> the matrix roof for fp32-equivalent FLOP is a third of the bf16 peak
         peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS / 3.0
-        return {"kernel": ("mrf_conv_mfma_f32_kernel" if dtype == "f32" else "conv_mfma_f32s_kernel (split-bf16 products)")
-                          + " (MRF ResBlock Conv1d steps)",
+        return {"kernel": ("fp32 MRF ResBlock kernels: mrf_conv_mfma_f32_kernel, mrf_pair_f32_kernel (fused conv pairs, C <= 64)" if dtype == "f32"
+                           else "conv_mfma_f32s_kernel (split-bf16 products)") + " (MRF ResBlock Conv1d steps)",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "hbm_achieved_gbs": gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": gbs / PEAK_HBM_GBS, **common}
     # bf16: the MRF launches taken together need more HBM time (bytes / 8 TB/s) than MFMA time

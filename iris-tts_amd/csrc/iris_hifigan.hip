@@ -433,10 +433,9 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
         // ---- fused conv pairs (mrf_pair_f32.h; C = 32 / 64, exact fp32): conv1 -> xt in LDS -> conv2 + residual in ONE launch,
         // bit for bit the two separate launches.  A fused pair cannot run in place, so the running x of a branch alternates
         // between its y and xt buffers, arranged so that the last fused pair leaves it in y (where the separate launches and
-        // the next layer expect it).  Taken for SMALL problems only -- those whose last step would not be the persistent
-        // kernel's summing launch anyway (one-branch-per-block modes) and for which pair_f32_plan measured the fused
-        // kernel ahead; on large problems the persistent kernel's cross-tile prefetch wins.  forward_until asking for a
-        // state after a conv1 gets the separate launches for that stage.
+        // the next layer expect it).  The last pair of the stage stays separate when its second step is the persistent
+        // kernel's summing launch (which forms the MRF mean; large problems).  forward_until asking for a state after a
+        // conv1 gets the separate launches for that stage.
         auto fill_pair = [&](PairLaunchF32& pa, int m, double& flops, double& wbytes) -> bool {
             memset(&pa, 0, sizeof(pa));
             flops = 0; wbytes = 0;
@@ -460,7 +459,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
             bool all_ok = true;
             for (int m = 0; m < nd && all_ok; ++m) {
                 PairLaunchF32 pa; double f, wb;
-                all_ok = fill_pair(pa, m, f, wb) && pair_f32_applicable(pa, nk) && pair_f32_plan(pa, nk).take;
+                all_ok = fill_pair(pa, m, f, wb) && pair_f32_applicable(pa, nk);
             }
             if (all_ok) {
                 bool sums = false;          // (the same decision as at the last step below)
@@ -475,9 +474,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                         sums = mrf_kernel_applicable(b, nk) && !pq.zpar && !pq.small;
                     }
                 }
-                // (summing launch in use: at C = 32 the first nd-1 pairs are still ahead fused up to ~100 k rows -- 200 frames:
-                //  174 vs 201 us for the stage's MRF steps; from ~700 frames on the persistent kernel is ahead by 1-4 %)
-                n_fused = !sums ? nd : ((st.C == 32 && (long long)L_out * B <= 100000) ? nd - 1 : 0);
+                n_fused = sums ? nd - 1 : nd;
             }
         }
         const float* cur_x[kMaxGroup];

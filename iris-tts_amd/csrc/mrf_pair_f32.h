@@ -13,6 +13,13 @@
 // leaves the CU: a block stages ONE window, runs conv1, keeps LeakyReLU(xt) in the same LDS region, runs conv2 from
 // there -- one launch, one window, one epilogue per pair instead of two of each.  The price: the last k-1 rows of
 // conv2's tile are computed and thrown away (they would need xt rows the block does not have), 1.6-7.8 % at 128 rows.
+// Measured against the separate launches (release builds, batch 1): the stage's MRF time falls by 17-28 % (C = 32) and
+// 0-16 % (C = 64) at 100-700 frames, by 7 % / 1 % at 1000 frames, 5 % / 1 % at batch 32 x 500.
+//
+// Job order: ALL jobs of the heaviest branch (k = 11) first, then k = 7, then k = 3.  Blocks are not persistent -- a block
+// is one (tile, branch) job of up to 40 us -- so the tail of a launch is as long as the jobs dispatched last: with the
+// k = 3 jobs last it is a quarter of what a tile-major order leaves (that order was 10-30 % slower whenever a launch
+// was more than about one round of the chip).
 //
 // Work split: a 256-thread block owns M = WT*MT*32 rows of xt and all C channels (WC*32 == C) of one branch of one
 // batch item; blocks advance by T_OUT = M - (k-1) rows.  Same LDS image as the other fp32 kernels (row stride C+4
@@ -43,6 +50,7 @@ struct PairLaunchF32 {
     int Gp, n_ct;         // packed-weight geometry (packed_groups / packed_cotiles of C)
     int n_jobs;           // tiles x branches (tiles = ceil(L / smallest T_OUT))
     int jobs_per_xcd;     // ceil(n_jobs / 8)
+    int z_major;          // job order: branch-major (heaviest first) instead of tile-major
 };
 
 // The MFMA loop of one conv over the LDS window: NG = KS * GPC groups of 8 channels; weight fragment n + DB is
@@ -96,11 +104,21 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_f32_kernel(const PairLaunc
     const int wt = wave / WC, wc = wave - wt * WC;
     const int lo = lane & 31, hi = lane >> 5;
 
-    // job -> (tile, branch): contiguous job ranges per XCD (neighbouring tiles share halo rows through that XCD's L2)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int job = xcd * a.jobs_per_xcd + slot;
-    if (job >= a.n_jobs) return;
-    const int tile = job / a.nz, zr = job - tile * a.nz;
+    // job -> (tile, branch).  z_major: all jobs of the heaviest branch first (the tail of the launch is then made of the
+    // short k = 3 blocks); else tile-major with contiguous job ranges per XCD (neighbouring tiles share halo rows through
+    // that XCD's L2)
+    int tile, zr;
+    if (a.z_major) {
+        const int job = (int)blockIdx.x;
+        if (job >= a.n_jobs) return;
+        const int tiles = a.n_jobs / a.nz;
+        zr = job / tiles; tile = job - zr * tiles;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int job = xcd * a.jobs_per_xcd + slot;
+        if (job >= a.n_jobs) return;
+        tile = job / a.nz; zr = job - tile * a.nz;
+    }
     const int z = a.nz - 1 - zr;                      // heaviest branch first
     PairProblemF32 p = a.p[0];
     if (z == 1) p = a.p[1];
@@ -243,20 +261,14 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_f32_kernel(const PairLaunc
 #endif
 struct PairTileF32 { int WT, WC, MT, MINB, M; };
 
-// What was measured (release builds, batch 1, profiles/r02zd_pair_f32_ab.txt): the fused kernel wins where a launch is about
-// ONE round of the chip -- a block is not persistent, so it pays its window load and its epilogue in the open, which
-// the other blocks of a CU cover; over several rounds the persistent kernel's cross-tile prefetch is ahead again.
-//   C = 32: 128-row tiles at four blocks per CU: 12-28 % ahead of the separate launches up to 400 frames (and level with
-//           them at 1000); taken for every problem that is small enough not to use the summing launch (see the caller).
-//   C = 64: 128-row tiles, or 64-row tiles when those would leave CUs without work; ahead (10-18 %) while the launch has at
-//           most three blocks per CU, behind (10-30 %) beyond -- taken up to there.
-// Taller tiles (256 rows at C = 32, 192 at C = 64: fewer rows thrown away) only pay on large problems, where the fused
-// kernel is level with the persistent one at C = 32 (109 vs 111 TFLOP/s at batch 1, 122 vs 117 at batch 32) and behind at
-// C = 64 (117 vs 124): not instantiated.
-struct PairPlanF32 { bool take; PairTileF32 tile; long long tiles; };
+// Tile height (release builds, profiles/r02zd_*, r02zh_*): 128 rows -- four blocks per CU at C = 32, three at C = 64; 64 rows at
+// C = 64 when 128 would leave CUs without work (short inputs: the launch time is then one block's serial time, which is
+// proportional to the tile height).  Taller tiles (256 / 192 rows: fewer rows thrown away) made no difference on large
+// problems (+-1 %) and are not instantiated.
+struct PairPlanF32 { PairTileF32 tile; long long tiles; };
 
 inline PairPlanF32 pair_f32_plan(const PairLaunchF32& a, int nz) {
-    PairPlanF32 pl; pl.take = false; pl.tiles = 0; pl.tile = PairTileF32{4, 1, 1, 4, 128};
+    PairPlanF32 pl;
     int kmax = 1;
     for (int j = 0; j < nz; ++j) if (a.p[j].ks > kmax) kmax = a.p[j].ks;
     const int n_cu = device_cu_count();
@@ -264,17 +276,15 @@ inline PairPlanF32 pair_f32_plan(const PairLaunchF32& a, int nz) {
     if (a.C == 32) {
         pl.tile = PairTileF32{4, 1, 1, 4, 128};
         pl.tiles = tiles_of(128);
-        pl.take = true;
-    } else if (a.C == 64) {
+    } else {
         pl.tile = PairTileF32{2, 2, 2, 3, 128};
         pl.tiles = tiles_of(128);
         if (pl.tiles * nz * a.B < 2LL * n_cu) { pl.tile = PairTileF32{2, 2, 1, 4, 64}; pl.tiles = tiles_of(64); }
-        pl.take = pl.tiles * nz * a.B <= 3LL * n_cu;
     }
     return pl;
 }
 
-// True when the pair launch `a` (nz branches, a.C channels) can take the fused kernel (whether it should: pair_f32_plan).
+// True when the pair launch `a` (nz branches, a.C channels) can take the fused kernel.
 inline bool pair_f32_applicable(const PairLaunchF32& a, int nz) {
     if (nz < 1 || nz > 4 || (a.C != 32 && a.C != 64)) return false;
     if (!(a.slope >= 0.f && a.slope <= 1.f)) return false;                        // LeakyReLU is evaluated as max(v, slope*v)
@@ -307,6 +317,7 @@ inline hipError_t launch_pair_f32(PairLaunchF32& a, int nz, hipStream_t stream) 
     if (n_jobs > 0x3fffffffLL) return hipErrorInvalidValue;
     a.n_jobs = (int)n_jobs;
     a.jobs_per_xcd = (int)((n_jobs + 7) / 8);
+    a.z_major = IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_ZMAJOR", 1);     // (tile-major: 10-20 % slower once a launch is more than one round)
     const size_t lds_bytes = (size_t)(t.M + span) * (a.C + 4) * sizeof(float);
     dim3 grid((unsigned)(a.jobs_per_xcd * 8), (unsigned)a.B, 1u), block(256);
 #define IRIS_PAIR_F32_CASE(WT_, WC_, MT_, C_, MINB_)                                                         \
