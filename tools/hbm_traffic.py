@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """HBM traffic per dispatch of the last forward from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
 usage: tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [plan]
-plan = one letter per launch of a forward: P conv_pre, U upsample, M MRF launch, O conv_post.  Default: the fp32 path
-(P + 4 x (U + 6 M) + O = 30 launches); the bf16 path with fused conv pairs at C <= 128 is PUMMMMMMUMMMUMMMUMMMO (21).
+plan = one letter per launch of a forward: P conv_pre, U upsample, M MRF launch, O conv_post.  Default: the fp32 path of a
+large problem (P + 2 x (U + 6 M) + 2 x (U + 4 M) + O = 26 launches: the C = 64 / 32 stages run two fused conv pairs and the
+two steps of the last pair); the bf16 path with fused conv pairs at C <= 128 is PUMMMMMMUMMMUMMMUMMMO (21).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2*FETCH_SIZE*1024;
 WRITE_SIZE*1024 is exact."""
 import collections, csv, json, sys
@@ -14,7 +15,7 @@ def load(path, counter):
             d[int(r["Dispatch_Id"])] = (r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"]))
     return list(d.values())
 
-plan = sys.argv[4] if len(sys.argv) > 4 else "P" + ("U" + "M" * 6) * 4 + "O"
+plan = sys.argv[4] if len(sys.argv) > 4 else "P" + ("U" + "M" * 6) * 2 + ("U" + "M" * 4) * 2 + "O"
 n = len(plan)
 fetch, write = load(sys.argv[1], "FETCH_SIZE")[-n:], load(sys.argv[2], "WRITE_SIZE")[-n:]
 assert len(fetch) == len(write) == n, (len(fetch), len(write))
