@@ -138,7 +138,7 @@ class GeneratorEngine:
     # -- hipGraph replay ---------------------------------------------------------------------------
     def forward_graph(self, mel: torch.Tensor, dtype: Optional[str] = None) -> torch.Tensor:
         """Same result as ``forward`` but the launches of one forward are captured once per
-        (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 30
+        (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 24-30
         kernel launches, and the inter-kernel gaps shrink to the graph's own.  ``iris_hifigan_forward`` is
         capture-safe by construction (no allocation, no synchronisation, caller's stream).  The returned
         tensor is the graph's static output buffer: it is overwritten by the next replay of the same shape.
