@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define IRIS_HIFIGAN_ABI_VERSION 2
+#define IRIS_HIFIGAN_ABI_VERSION 3
 #define IRIS_HIFIGAN_MAX_STAGES 8    /* upsample stages            */
 #define IRIS_HIFIGAN_MAX_KERNELS 8   /* MRF branches per stage     */
 #define IRIS_HIFIGAN_MAX_DILATIONS 8 /* conv pairs per ResBlock    */
@@ -117,7 +117,16 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
                             uint64_t n_weights, iris_hifigan_handle** out);
 int32_t iris_hifigan_destroy(iris_hifigan_handle* h);
 
-/* Activation workspace needed by one forward of [B, in_channels, T]. */
+/* create uploads the fp32 MFMA packing of the weights only.  The packings the other arithmetic needs (bf16 fragments for
+ * IRIS_HIFIGAN_BF16, hi/mid bf16 planes for IRIS_HIFIGAN_F32_SPLIT, the 16x16 fragments of the short-input fp32 kernel for
+ * IRIS_HIFIGAN_F32) are built on the first use of that dtype: by this call, or by the first forward of the dtype (which is
+ * then synchronous and allocates once).  Call prepare before capturing forwards of a dtype into a hipGraph. */
+int32_t iris_hifigan_prepare(iris_hifigan_handle* h, int32_t dtype);
+
+/* Activation workspace needed by one forward of [B, in_channels, T].  Batch items are independent: a batch of more than
+ * 65,536 mel frames in all runs as consecutive passes over sub-batches that share the workspace, so the figure is bounded
+ * (fp32: 229 KB per frame of ONE pass, at most ~15 GB; bf16 half of that) instead of growing with the batch; one item
+ * longer than that still needs its own length (split long utterances along time with iris.streaming). */
 int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, int32_t T,
                                      int32_t dtype, uint64_t* bytes);
 
@@ -168,6 +177,31 @@ int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop);
 int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled);
 int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_record* out,
                                   int32_t capacity, int32_t* n_launches);
+/* paused != 0: forwards record nothing until resumed; the records collected so far are kept (set_profiling would
+ * reset them).  For forwards that are captured into a hipGraph (no events inside a capture). */
+int32_t iris_hifigan_pause_profiling(iris_hifigan_handle* h, int32_t paused);
+
+/* ---- launch plan of one forward, computed on the host alone (no device, nothing launched) ----
+ * Runs the forward's own argument checks, workspace layout and launch planning for [B, in_channels, T] in `dtype` on a
+ * chip of `cu_count` compute units (0 = 256, MI355X) and reports every launch it would issue, in order.  Used by the CPU
+ * tests (address/undefined-behaviour sanitizer sweeps over the index arithmetic of the plans) and for inspection. */
+#define IRIS_HIFIGAN_MAX_PLAN_LAUNCHES 96
+typedef struct iris_hifigan_plan_launch {
+    char kernel[80];        /* kernel (template) name as the launch site spells it */
+    uint32_t grid[3];
+    uint32_t block;
+    uint64_t lds_bytes;     /* dynamic LDS per block */
+} iris_hifigan_plan_launch;
+typedef struct iris_hifigan_plan {
+    uint64_t workspace_bytes;
+    int32_t n_launches;     /* over all passes; may exceed IRIS_HIFIGAN_MAX_PLAN_LAUNCHES: only that many are described */
+    int32_t cu_count;
+    int32_t passes;         /* sub-batch passes the forward runs as (1 unless B * T exceeds 65,536 frames) */
+    int32_t reserved;
+    iris_hifigan_plan_launch launches[IRIS_HIFIGAN_MAX_PLAN_LAUNCHES];
+} iris_hifigan_plan;
+int32_t iris_hifigan_describe_plan(const iris_hifigan_config* cfg, int32_t B, int32_t T, int32_t dtype, int32_t cu_count,
+                                   iris_hifigan_plan* out);
 
 /* ---- single-layer entry points (bring-up and parity tests; synchronous, they allocate) ----
  * x_dev/y_dev/res_dev are channels-last [B, L, C]; weights/bias are HOST arrays in the
@@ -201,14 +235,18 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
                                  int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
                                  float slope, int32_t plan, void* stream);
 
-/* One ResBlock conv PAIR of the three branches in one launch, exact fp32 (csrc/mrf_pair_f32.h; C = 32 or 64,
- * k[j] in {3, 7, 11}): y_j = Conv1d_{k[j], 1}(LeakyReLU(Conv1d_{k[j], dil[j]}(LeakyReLU(x_j)))) + x_j
- * (hifigan_pretrained.py:64-71), bit for bit what two iris_hifigan_op_mrf_step calls produce.  y_dev must not
- * alias x_dev.  Returns IRIS_HIFIGAN_UNSUPPORTED for other shapes. */
+/* One ResBlock conv PAIR of the three branches in one launch, exact fp32 (csrc/mrf_pair_f32.h, mrf_pair_f32_pf.h; C = 32
+ * or 64, k[j] in {3, 7, 11}): y_j = Conv1d_{k[j], 1}(LeakyReLU(Conv1d_{k[j], dil[j]}(LeakyReLU(x_j)))) + x_j
+ * (hifigan_pretrained.py:64-71), bit for bit what two iris_hifigan_op_mrf_step calls produce.
+ * mode: 0 = one block per (tile, branch) job; 1 = persistent blocks that prefetch the next job's window and draw their
+ * jobs from a device counter; 2 = the same with a fixed job stride.
+ * mean_dev != NULL (modes 1, 2) makes it the LAST pair of a stage: only ((y_0 + y_1) + y_2) / 3 is stored, into mean_dev
+ * (hifigan_pretrained.py:131-137; y_dev is then unused).  No y_dev[i] / mean_dev may alias an x_dev[j].
+ * Returns IRIS_HIFIGAN_UNSUPPORTED for other shapes. */
 int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* w1_host, const float* const* b1_host,
                                  const float* const* w2_host, const float* const* b2_host, float* const* y_dev,
-                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
-                                 float slope, void* stream);
+                                 float* mean_dev, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, int32_t mode, void* stream);
 
 /* bf16 variants of the two layers above (dtype IRIS_HIFIGAN_BF16): x_dev / res_dev / y_dev are bf16
  * channels-last [B, L, C] (C_in % 8 == 0, C_out % 4 == 0); host weights are fp32 in the reference layout and are

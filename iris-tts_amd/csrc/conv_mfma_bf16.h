@@ -470,14 +470,9 @@ __global__ void __launch_bounds__(256) conv_post_tanh_bf16_kernel(const PostLaun
 inline hipError_t launch_conv_post_bf16(const PostLaunch& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)(kPostTile + a.k - 1) * (a.C | 1) * sizeof(float);
     if (lds_bytes > 160 * 1024 || (a.C & 7)) return hipErrorInvalidValue;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_post_tanh_bf16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
     dim3 grid((unsigned)((a.L + kPostTile - 1) / kPostTile), (unsigned)a.B), block(256);
-    hipLaunchKernelGGL(conv_post_tanh_bf16_kernel, grid, block, lds_bytes, stream, a);
-    return hipGetLastError();
+    { const hipError_t e__ = ::iris::launch_kernel(conv_post_tanh_bf16_kernel, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; }
+    return hipSuccess;       
 }
 
 // ---- host side: weight packing ---------------------------------------------------------------------
@@ -606,14 +601,8 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
 #define IRIS_B16_LAUNCH(...)                                                                      \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
-        if (lds_bytes > 64 * 1024) {                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                               (int)lds_bytes);                                   \
-            if (e != hipSuccess) return e;                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
-        return hipGetLastError();                                                                 \
+        { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+        return hipSuccess;                                                                        \
     } while (0)
 #define IRIS_B16_CASE(WT_, WC_, MT_, NT_, CIC_, MINB_)                                            \
     if (t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.CIC == CIC_ && t.MINB == MINB_) \

@@ -29,6 +29,7 @@
 // blockIdx.x % nz selects one of up to 8 independent problems of identical shape (the MRF branches of
 // one stage, kernel sizes 3/7/11: three ResBlocks advance in one launch) or the ConvTranspose phase.
 #pragma once
+#include "device_info.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -85,6 +86,7 @@ struct ConvLaunch {
     int n_ct;            // number of 32-wide C_out tiles in the packed weights
     unsigned* dyn_counter;  // MRF kernel: when set (zero at launch), blocks take their 2nd, 3rd, ... tile from this
                             // counter instead of a fixed stride (large batches: evens out slow and fast CUs)
+    int stagger, stagger_mod;  // diagnostics only (IRIS_HIFIGAN_STAGGER): blocks of the second residency generation sleep first
     int zb1, zb2;           // MRF kernel, one-branch-per-block mode: blocks [0, zb1) serve branch 2 (k = 11),
                             // [zb1, zb2) branch 1 (k = 7), [zb2, gridDim.x) branch 0 (k = 3)
 };
@@ -207,10 +209,56 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
     const f32x4* wlane = wp + (size_t)ct * 64 + lane;
     const size_t wstep = (a.ablate & 2) ? 0 : (size_t)a.n_ct * 64;  // f32x4 elements per (tap, group)
 
+    // Chunk prefetch (layers with several C_in chunks and a short window: the ConvTranspose1d phases, PostNet): the quads of
+    // chunk c+1 are requested during the MFMAs of chunk c -- one per group, behind that group's weight request: vmcnt retires
+    // in order, so spread out each of them only delays the weight wait two groups later -- and written to LDS after them.
+    // Without it a block alternated between waiting for a chunk (an L2 round trip) and 16-32 groups of MFMAs: the
+    // upsamplers ran at half the fp32 MFMA roof.
+    constexpr int QPR = CIC / 4;
+    constexpr int PQ = 5;                                   // prefetched quads per thread: windows up to 256 * PQ / QPR rows
+    const int tid = threadIdx.x;
+    const bool pf = KS > 0 && !a.x_channels_first && (a.C_in & 3) == 0 && a.in_act != IN_ACT_MRF_LRELU && a.C_in > CIC &&
+                    R * QPR <= 256 * PQ && !(a.ablate & (1 | 64));      // (diagnostic builds: ablate bit 64 = no chunk prefetch)
+    f32x4 pre[PQ];
+    const float* pre_ptr[PQ];                               // quad i of chunk 0 (or the tensor's base when the quad is padding)
+    bool pre_ok[PQ];
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) {
+        const int idx = i * 256 + tid;
+        const int r = idx / QPR, q = idx - r * QPR;
+        const int row = in_row0 + r;
+        pre_ok[i] = pf && idx < R * QPR && row >= 0 && row < a.L_in;
+        pre_ptr[i] = p.x + (pre_ok[i] ? ((size_t)b * a.L_in + row) * a.C_in + 4 * q : 0);
+    }
+    auto pf_issue_one = [&](int i, int c0n) {               // (always a valid address: the padding quads re-read the base)
+        const bool ok = pre_ok[i] && c0n + 4 * ((i * 256 + tid) % QPR) < a.C_in;
+        pre[i] = *reinterpret_cast<const f32x4*>(pre_ptr[i] + (ok ? c0n : 0));
+    };
+    auto pf_write = [&](int c0n) {
+#pragma unroll
+        for (int i = 0; i < PQ; ++i) {
+            const int idx = i * 256 + tid;
+            const int r = idx / QPR, q = idx - r * QPR;
+            if (idx < R * QPR) {
+                const bool ok = pre_ok[i] && c0n + 4 * q < a.C_in;
+                f32x4 v = ok ? pre[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.in_act == IN_ACT_LRELU) v = lrelu4(v, a.slope);
+                *reinterpret_cast<f32x4*>(lds + r * S + 4 * q) = v;
+            }
+        }
+    };
+
     for (int c0 = 0; c0 < a.C_in; c0 += CIC) {
         if (c0 > 0) __syncthreads();
-        if (!(a.ablate & 1)) stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
+        if (pf && c0 > 0) pf_write(c0);
+        else if (!(a.ablate & 1)) stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
         __syncthreads();
+        const bool pf_next = pf && c0 + CIC < a.C_in;
+        const int c0n = pf_next ? c0 + CIC : 0;             // (no next chunk: the requests below re-read the base, unused)
+        if (!wave_active && pf_next) {
+#pragma unroll
+            for (int i = 0; i < PQ; ++i) pf_issue_one(i, c0n);
+        }
         if (wave_active) {
             const int g0 = c0 >> 3;
             // One "group" = 8 input channels of one tap = 4*MT MFMAs.  Fragments of group n+1
@@ -245,17 +293,23 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
                 for (int n = 0; n < NG; n += 2) {
                     if (n + 1 < NG) load_a(av1, n + 1);
                     if (n + 2 < NG) bw2 = *b_ptr(n + 2);
+                    if (n < PQ) { if (pf) pf_issue_one(n, c0n); }
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_group(av0, bw0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (n + 1 < NG) {
                         if (n + 2 < NG) load_a(av0, n + 2);
                         if (n + 3 < NG) bw0 = *b_ptr(n + 3);
+                        if (n + 1 < PQ) { if (pf) pf_issue_one(n + 1, c0n); }
                         __builtin_amdgcn_sched_barrier(0);
                         mfma_group(av1, bw1);
                         __builtin_amdgcn_sched_barrier(0);
                         bw1 = bw0; bw0 = bw2;                  // rotate: bw0 <- group n+2, bw1 <- group n+3
                     }
+                }
+                if (pf) {
+#pragma unroll
+                    for (int i = NG; i < PQ; ++i) pf_issue_one(i, c0n);   // (fewer groups than quads: the rest behind the loop)
                 }
             } else {
                 for (int n = 0; n < n_groups; ++n) {
@@ -473,23 +527,6 @@ inline ConvTile pick_tile(int C_in, int C_out) {
     return t;
 }
 
-// Compute units of the CURRENT HIP device (launch plans are sized per device: a process may hold engines on
-// several GPUs, so the count is cached per device ordinal, not per process).
-inline int device_cu_count() {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-    const int slot = dev < 64 ? dev : 63;
-    int n = dev < 64 ? cache[slot].load(std::memory_order_relaxed) : 0;
-    if (n <= 0) {
-        n = 256;
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n <= 0) n = 256;
-        if (dev < 64) cache[slot].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
-
 // Fills the derived fields of `a` (n_co_blk, Gp, n_ct) and launches. `nz` = problems or phases.
 inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
@@ -512,7 +549,10 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const int n_cu = device_cu_count();
     const int mt_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_CONV_MT", 0);
     const long long blocks2 = (long long)((a.n_idx + t.T_BLK - 1) / t.T_BLK) * a.n_co_blk * nz * a.B;
-    const int MT = mt_env ? mt_env : (blocks2 < 2LL * n_cu ? 1 : 2);
+    // (the last ConvTranspose1d -- K = 2 taps x 64 channels, 32 output channels: three quarters of a block's life is window load
+    //  and store -- runs better as four 35 KB blocks per CU than as two 70 KB ones: 50 -> 43 us at batch 1 x 1000 frames)
+    const bool tall_small_k = a.z_is_phase && t.WT == 4 && a.C_in <= 64;
+    const int MT = mt_env ? mt_env : ((blocks2 < 2LL * n_cu || tall_small_k) ? 1 : 2);
     const int T_BLK = t.WT * MT * 32;
     // conv_pre of the V1 generator (80 mel bins, channels-first -> 512): one 80-channel chunk instead of 64 + 16.  The launch
     // has 64-128 blocks, so its time is one block's serial time, and each chunk costs a staging round trip and two barriers.
@@ -525,13 +565,7 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
 #define IRIS_LAUNCH_K(...)                                                                        \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
-        if (lds_bytes > 64 * 1024) {                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                               (int)lds_bytes);                                   \
-            if (e != hipSuccess) return e;                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+        { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
     } while (0)
 #define IRIS_LAUNCH(WT_, WC_, CIC_)                                                               \
     do { if (MT == 1) IRIS_LAUNCH_K(conv_mfma_f32_kernel<WT_, WC_, 1, CIC_>);                     \
@@ -543,7 +577,7 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     else                               IRIS_LAUNCH(1, 4, 64);
 #undef IRIS_LAUNCH_K
 #undef IRIS_LAUNCH
-    return hipGetLastError();
+    return hipSuccess;       // (every launch above has reported its own status)
 }
 
 }  // namespace iris

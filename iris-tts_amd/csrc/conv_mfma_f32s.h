@@ -398,14 +398,8 @@ inline hipError_t launch(Launch& a, int nz, hipStream_t stream) {
 #define IRIS_S3_LAUNCH(...)                                                                       \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
-        if (lds_bytes > 64 * 1024) {                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                               (int)lds_bytes);                                   \
-            if (e != hipSuccess) return e;                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
-        return hipGetLastError();                                                                 \
+        { const hipError_t e__ = ::iris::launch_kernel_named("conv_mfma_f32s_kernel", kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+        return hipSuccess;                                                                        \
     } while (0)
 #define IRIS_S3_CASE(WT_, WC_, NT_, CIC_)                                                         \
     if (t.WT == WT_ && t.WC == WC_ && t.NT == NT_) {                                              \

@@ -179,14 +179,19 @@ __global__ void __launch_bounds__(256) conv_post_tanh_kernel(const ConvPostLaunc
     a.y[(size_t)b * a.L + t] = tanhf(acc);
 }
 
+// True when the 16-byte-staging kernel can take the launch (32-bit buffer offsets inside one batch item's tensor).
+inline bool conv_post_rows_ok(const ConvPostLaunch& a, bool bf16_in) {
+    const long long blocks = (long long)((a.L + kPostTile - 1) / kPostTile) * a.B;
+    return (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64) && a.n_in <= 4 && blocks >= 1 && blocks <= 0x7fffffffLL &&
+           (double)a.L * a.C * (bf16_in ? 2 : 4) < 2147483648.0;
+}
+
 template <bool BF16_IN>
 inline hipError_t launch_conv_post_t(ConvPostLaunch a, hipStream_t stream) {
     a.tiles_per_item = (a.L + kPostTile - 1) / kPostTile;
     const long long blocks = (long long)a.tiles_per_item * a.B;
     if (blocks < 1 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int esz = BF16_IN ? 2 : 4;
-    const bool rows_ok = (a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64) && a.n_in <= 4 &&
-                         (double)a.L * a.C * esz < 2147483648.0;
+    const bool rows_ok = conv_post_rows_ok(a, BF16_IN);
     dim3 grid((unsigned)blocks), block(256);
     if (rows_ok) {
         const size_t lds_bytes = (size_t)(kPostTile + a.k - 1) * (a.C + 4) * sizeof(float);
@@ -194,13 +199,8 @@ inline hipError_t launch_conv_post_t(ConvPostLaunch a, hipStream_t stream) {
 #define IRIS_POST_CASE(C_)                                                                                   \
         if (a.C == C_) {                                                                                     \
             auto kfn = conv_post_rows_kernel<C_, BF16_IN>;                                                   \
-            if (lds_bytes > 64 * 1024) {                                                                     \
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-                if (e != hipSuccess) return e;                                                               \
-            }                                                                                                \
-            hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                                      \
-            return hipGetLastError();                                                                        \
+            { const hipError_t e__ = ::iris::launch_kernel_named("conv_post_rows_kernel", kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+            return hipSuccess;                                                                               \
         }
         IRIS_POST_CASE(8) IRIS_POST_CASE(16) IRIS_POST_CASE(32) IRIS_POST_CASE(64)
 #undef IRIS_POST_CASE
@@ -208,13 +208,8 @@ inline hipError_t launch_conv_post_t(ConvPostLaunch a, hipStream_t stream) {
     if (BF16_IN) return hipErrorInvalidValue;      // the bf16-storage path has no scalar fallback (C % 8 == 0 there)
     const size_t lds_bytes = (size_t)(kPostTile + a.k - 1) * (a.C | 1) * sizeof(float);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_post_tanh_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(conv_post_tanh_kernel<0>, grid, block, lds_bytes, stream, a);
-    return hipGetLastError();
+    { const hipError_t e__ = ::iris::launch_kernel(conv_post_tanh_kernel<0>, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; }
+    return hipSuccess;       
 }
 
 inline hipError_t launch_conv_post(const ConvPostLaunch& a, hipStream_t stream) { return launch_conv_post_t<false>(a, stream); }

@@ -11,9 +11,13 @@
 
 #include "../../include/iris_hifigan.h"
 #include "diag_env.h"
+#include "device_info.h"
+#include <new>
 
 namespace iris {
 
+constexpr int kPassFrames = 65536;       // mel frames (batch x frames) one pass of a forward processes: bounds the workspace
+int pass_items(int B, int T);             // batch items of one pass
 constexpr int kTileCounterWords = 256;   // per-launch next-tile counters of one forward (MRF kernel, large batches)
 
 // forward_until: stop after MRF step `step` of stage `stage` has been queued (stage < 0: run the whole forward)
@@ -50,6 +54,15 @@ int fail(int code, const char* fmt, ...);
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != IRIS_HIFIGAN_OK) return rc__; } while (0)
 
+// Every extern "C" body that can allocate runs between these: no C++ exception crosses the ABI (include/iris_hifigan.h).
+#define IRIS_ABI_BEGIN try {
+#define IRIS_ABI_END                                                                                              \
+    } catch (const std::bad_alloc&) {                                                                             \
+        return ::iris::fail(IRIS_HIFIGAN_OUT_OF_MEMORY, "host allocation failed (%s)", __func__);                 \
+    } catch (...) {                                                                                               \
+        return ::iris::fail(IRIS_HIFIGAN_HIP_ERROR, "unexpected C++ exception in %s", __func__);                  \
+    }
+
 struct ConvLayer {       // one Conv1d / ConvTranspose1d, weights resident on the device
     int kind = 0;                                     // 0 Conv1d, 1 ConvTranspose1d, 2 conv_post
     int C_in = 0, C_out = 0, k = 0, dil = 1, u = 1;  // u = stride of a ConvTranspose1d
@@ -84,8 +97,14 @@ struct iris_hifigan_handle {
     float* blob_w16 = nullptr;   // device: ResBlock conv weights in v_mfma_f32_16x16x4_f32 fragment order (small-problem kernel), or null
     int hop = 1;
     int device = 0;
+    // Weight packings beyond the fp32 MFMA one are built on the first use of the dtype that needs them
+    // (iris_hifigan_prepare): the reference-layout weights are kept on the host until every packing exists.
+    std::vector<float> ref_weights;
+    bool tried_w16 = false, tried_bf16 = false, tried_s3 = false;
+    bool host_only = false;     // iris_hifigan_describe_plan: no device memory behind the pointers, nothing is launched
     // profiling
     int profiling = 0;          // 0 off, 1 one record per launch, 2 the MRF launches of a stage share one record
+    int profiling_paused = 0;   // records are kept, forwards add none (hipGraph capture)
     std::vector<hipEvent_t> ev;          // event pool, n_ev in use
     size_t n_ev = 0;
     std::vector<iris_hifigan_launch_record> recs;
@@ -139,8 +158,9 @@ struct Prof {
         ++idx;
         return IRIS_HIFIGAN_OK;
     }
+    bool on() const { return h->profiling && !h->profiling_paused; }
     int begin(int kind, int stage, int step, double flops, double bytes) {
-        if (!h->profiling) return IRIS_HIFIGAN_OK;
+        if (!on()) return IRIS_HIFIGAN_OK;
         const bool grouped = h->profiling == 2 && kind == 2;
         if (pending) {
             iris_hifigan_launch_record& g = h->recs[idx];
@@ -162,7 +182,7 @@ struct Prof {
         return IRIS_HIFIGAN_OK;
     }
     int end() {
-        if (!h->profiling || pending) return IRIS_HIFIGAN_OK;
+        if (!on() || pending) return IRIS_HIFIGAN_OK;
         int rc = mark(&h->rec_ev[idx].second);
         if (rc != IRIS_HIFIGAN_OK) return rc;
         open = true;
@@ -171,6 +191,7 @@ struct Prof {
     }
     // end of a forward (or of forward_until): closes an open group and publishes the record count
     int finish() {
+        if (!on()) return IRIS_HIFIGAN_OK;
         int rc = close_group();
         if (rc != IRIS_HIFIGAN_OK) return rc;
         h->n_rec = idx;
@@ -179,7 +200,7 @@ struct Prof {
 };
 
 // ---- bf16-storage path (iris_hifigan_bf16.hip) ----
-int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob16
+int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host);   // packs + uploads blob16 (host_only: packs only)
 uint64_t bf16_workspace_bytes(const iris_hifigan_handle* h, int B, int T);
 int bf16_workspace_map(const iris_hifigan_handle* h, int B, int T, iris_hifigan_workspace_map* out);
 int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void* wav_dev,

@@ -27,6 +27,7 @@
 #include "mrf_conv_mfma_f32.h"
 #include "mrf_small_f32.h"
 #include "mrf_pair_f32.h"
+#include "mrf_pair_f32_pf.h"
 #include "conv_post.h"
 #include "postnet.h"
 
@@ -168,12 +169,25 @@ void init_launch(ConvLaunch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
 
 }  // namespace
 
+namespace iris {
+// Batch items one pass of a forward processes.  Batch items are independent, so a forward of a large batch runs as
+// consecutive passes over sub-batches that share ONE workspace: the workspace is bounded by kPassFrames mel frames
+// (229 KB per frame in fp32: 15 GB) instead of growing with the batch (58 GB at 256 x 1000 frames), at no cost in
+// throughput -- the kernels are at their large-batch efficiency from ~16,000 frames on.
+int pass_items(int B, int T) {
+    if (B <= 1 || T <= 0) return B;
+    const long long fit = kPassFrames / T;
+    return (int)(fit < 1 ? 1 : (fit < B ? fit : B));
+}
+}  // namespace iris
+
 extern "C" {
 
 int32_t iris_hifigan_abi_version(void) { return IRIS_HIFIGAN_ABI_VERSION; }
 const char* iris_hifigan_last_error(void) { return iris::g_err; }
 
 int32_t iris_hifigan_weight_count(const iris_hifigan_config* cfg, uint64_t* count) {
+    IRIS_ABI_BEGIN
     TRY(validate(cfg));
     if (!count) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "count is NULL");
     iris_hifigan_handle tmp;
@@ -181,22 +195,27 @@ int32_t iris_hifigan_weight_count(const iris_hifigan_config* cfg, uint64_t* coun
     build_layers(&tmp);
     *count = ref_weight_count(&tmp);
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights_host,
                             uint64_t n_weights, iris_hifigan_handle** out) {
+    IRIS_ABI_BEGIN
     TRY(validate(cfg));
     if (!weights_host || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    struct Owner {                      // frees a half-built generator on every early return, exceptions included
+        iris_hifigan_handle* h = nullptr;
+        ~Owner() { if (h) (void)iris_hifigan_destroy(h); }
+    } owner;
     iris_hifigan_handle* h = new (std::nothrow) iris_hifigan_handle;
     if (!h) return fail(IRIS_HIFIGAN_OUT_OF_MEMORY, "host allocation failed");
+    owner.h = h;
     h->cfg = *cfg;
     build_layers(h);
     const uint64_t expect = ref_weight_count(h);
-    if (n_weights != expect) {
-        delete h;
+    if (n_weights != expect)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "weight blob has %llu values, config needs %llu",
                     (unsigned long long)n_weights, (unsigned long long)expect);
-    }
     std::vector<float> host(h->blob_floats, 0.f);
     const float* src = weights_host;
     for_each_layer(h, [&](ConvLayer& l) {
@@ -219,47 +238,23 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
     if (e == hipSuccess) e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)iris_hifigan_destroy(h);          // frees whatever was allocated so far
+    if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "weight upload failed: %s", hipGetErrorString(e));
-    }
     if (hipMalloc(&h->tile_counters, kTileCounterWords * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
-    {
-        // second packing of the ResBlock conv weights for the small-problem kernel (mrf_small_f32.h); optional:
-        // without it short inputs simply take the persistent kernel
-        size_t off16 = 0;
-        for (auto& st : h->stages)
-            for (size_t j = 0; j < st.c1.size(); ++j)
-                for (int half = 0; half < 2; ++half)
-                    for (auto& l : (half == 0 ? st.c1[j] : st.c2[j]))
-                        if ((l.C_in & 15) == 0 && (l.C_out & 15) == 0) { l.w16f_off = off16; off16 += packed16_conv1d_floats(l.C_in, l.C_out, l.k); }
-        if (off16 > 0) {
-            std::vector<float> host16(off16);
-            const float* src16 = weights_host;
-            for_each_layer(h, [&](ConvLayer& l) {
-                if (l.w16f_off != (size_t)-1) pack_conv1d_weights16(src16, l.C_in, l.C_out, l.k, host16.data() + l.w16f_off);
-                src16 += l.ref_w_floats + l.C_out;
-            });
-            if (hipMalloc(&h->blob_w16, off16 * sizeof(float)) != hipSuccess ||
-                hipMemcpy(h->blob_w16, host16.data(), off16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-                if (h->blob_w16) (void)hipFree(h->blob_w16);
-                h->blob_w16 = nullptr;
-            }
-        }
-    }
-    int rc16 = bf16_build_blob(h, weights_host);
-    if (rc16 == IRIS_HIFIGAN_OK) rc16 = f32s_build_blob(h, weights_host);
-    if (rc16 != IRIS_HIFIGAN_OK) {
-        (void)iris_hifigan_destroy(h);
-        return rc16;
-    }
+    // the other packings (16 x 16 fragments of the small-problem kernel, bf16, split-bf16: ~150 MB together) are built by
+    // iris_hifigan_prepare / on the first forward of the dtype that needs them
+    h->ref_weights.assign(weights_host, weights_host + n_weights);
+    owner.h = nullptr;
     *out = h;
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     if (!h) return IRIS_HIFIGAN_OK;
+    if (h->host_only) { delete h; return IRIS_HIFIGAN_OK; }
+    DeviceGuard guard(h->device);       // the allocations belong to the handle's device, whatever is current now
     for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
     if (h->blob) (void)hipFree(h->blob);
     if (h->blob16) (void)hipFree(h->blob16);
@@ -268,6 +263,68 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
     if (h->tile_counters) (void)hipFree(h->tile_counters);
     delete h;
     return IRIS_HIFIGAN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// second packing of the ResBlock conv weights for the small-problem kernel (mrf_small_f32.h): float offsets, then
+// (with weights) the packed fragments.  Optional: without it short inputs simply take the persistent kernel.
+size_t assign_w16_offsets(iris_hifigan_handle* h) {
+    size_t off16 = 0;
+    for (auto& st : h->stages)
+        for (size_t j = 0; j < st.c1.size(); ++j)
+            for (int half = 0; half < 2; ++half)
+                for (auto& l : (half == 0 ? st.c1[j] : st.c2[j]))
+                    if ((l.C_in & 15) == 0 && (l.C_out & 15) == 0) { l.w16f_off = off16; off16 += packed16_conv1d_floats(l.C_in, l.C_out, l.k); }
+    return off16;
+}
+
+void build_w16(iris_hifigan_handle* h, const float* weights_host) {
+    const size_t off16 = assign_w16_offsets(h);
+    if (off16 == 0) return;
+    std::vector<float> host16(off16);
+    const float* src16 = weights_host;
+    for_each_layer(h, [&](ConvLayer& l) {
+        if (l.w16f_off != (size_t)-1) pack_conv1d_weights16(src16, l.C_in, l.C_out, l.k, host16.data() + l.w16f_off);
+        src16 += l.ref_w_floats + l.C_out;
+    });
+    if (hipMalloc(&h->blob_w16, off16 * sizeof(float)) != hipSuccess ||
+        hipMemcpy(h->blob_w16, host16.data(), off16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (h->blob_w16) (void)hipFree(h->blob_w16);
+        h->blob_w16 = nullptr;
+    }
+}
+
+// Builds the weight packings `dtype` needs, once.  Synchronous (allocates and uploads): the first forward of a dtype
+// does it itself; a caller that captures forwards into a hipGraph calls iris_hifigan_prepare beforehand.
+int ensure_prepared(iris_hifigan_handle* h, int32_t dtype) {
+    const bool want_w16 = (dtype == IRIS_HIFIGAN_F32 || dtype == IRIS_HIFIGAN_F32_SPLIT) && !h->tried_w16;
+    const bool want_bf16 = dtype == IRIS_HIFIGAN_BF16 && !h->tried_bf16;
+    const bool want_s3 = dtype == IRIS_HIFIGAN_F32_SPLIT && !h->tried_s3;
+    if (!want_w16 && !want_bf16 && !want_s3) return IRIS_HIFIGAN_OK;
+    if (h->ref_weights.empty()) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "generator holds no weights to pack");
+    if (want_w16)  { h->tried_w16 = true; build_w16(h, h->ref_weights.data()); }
+    if (want_bf16) { h->tried_bf16 = true; TRY(bf16_build_blob(h, h->ref_weights.data())); }
+    if (want_s3)   { h->tried_s3 = true; TRY(f32s_build_blob(h, h->ref_weights.data())); }
+    if (h->tried_w16 && h->tried_bf16 && h->tried_s3) std::vector<float>().swap(h->ref_weights);   // every packing exists
+    return IRIS_HIFIGAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t iris_hifigan_prepare(iris_hifigan_handle* h, int32_t dtype) {
+    IRIS_ABI_BEGIN
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16 && dtype != IRIS_HIFIGAN_F32_SPLIT)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
+    DeviceGuard guard(h->device);
+    if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
+    return ensure_prepared(h, dtype);
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop) {
@@ -280,6 +337,7 @@ int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, in
                                      int32_t dtype, uint64_t* bytes) {
     if (!h || !bytes) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
+    B = pass_items(B, T);                                   // a large batch runs as passes over sub-batches sharing the workspace
     if (dtype == IRIS_HIFIGAN_BF16) { *bytes = bf16_workspace_bytes(h, B, T); return IRIS_HIFIGAN_OK; }
     if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_F32_SPLIT)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
@@ -290,13 +348,21 @@ int32_t iris_hifigan_workspace_bytes(const iris_hifigan_handle* h, int32_t B, in
 int32_t iris_hifigan_set_profiling(iris_hifigan_handle* h, int32_t enabled) {
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+    h->profiling_paused = 0;
     h->n_rec = 0;
     h->n_ev = 0;
     return IRIS_HIFIGAN_OK;
 }
 
+int32_t iris_hifigan_pause_profiling(iris_hifigan_handle* h, int32_t paused) {
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    h->profiling_paused = paused != 0;
+    return IRIS_HIFIGAN_OK;
+}
+
 int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_record* out,
                                   int32_t capacity, int32_t* n_launches) {
+    IRIS_ABI_BEGIN
     if (!h || !n_launches) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     *n_launches = h->n_rec;
     for (int i = 0; i < h->n_rec; ++i) {
@@ -306,6 +372,7 @@ int32_t iris_hifigan_read_profile(iris_hifigan_handle* h, iris_hifigan_launch_re
         if (out && i < capacity) out[i] = h->recs[i];
     }
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 }  // extern "C"
@@ -318,8 +385,6 @@ int check_forward_args(const iris_hifigan_handle* h, const void* mel_dev, int32_
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_BF16 && dtype != IRIS_HIFIGAN_F32_SPLIT)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
-    if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
-        return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;
     if (!mel_dev || !workspace_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
@@ -341,13 +406,17 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
     const float* blob = h->blob;
     const float slope = h->cfg.lrelu_slope;
     const int nk = h->cfg.num_kernels;
-    Prof prof{h, stream, h->profiling ? h->n_rec : 0};
+    Prof prof{h, stream, (h->profiling && !h->profiling_paused) ? h->n_rec : 0};
     const double fB = (double)B;
     // large batches: the MRF kernel's blocks draw tiles from per-launch counters (mrf_conv_mfma_f32.h); one
     // memset per forward zeroes them.  Below ~2000 frames no launch has enough tiles per block to use them.
     const bool dyn_tiles = h->tile_counters && (long long)B * T >= 2000 &&
-                           (int)h->stages.size() * 2 * h->cfg.num_dilations[0] <= kTileCounterWords;
-    if (dyn_tiles) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, kTileCounterWords * sizeof(unsigned), stream));
+                           (int)h->stages.size() * 2 * h->cfg.num_dilations[0] <= kTileCounterWords / 2;
+    // the persistent pair kernels draw jobs from one counter word per launch (upper half of the array); a forward too short
+    // to use either kind of counter skips the memset
+    const bool pf_counters = h->tile_counters && (long long)B * T >= 100 &&
+                             (int)h->stages.size() * h->cfg.num_dilations[0] <= kTileCounterWords / 2;
+    if ((dyn_tiles || pf_counters) && !h->host_only) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, kTileCounterWords * sizeof(unsigned), stream));
 
     // ---- conv_pre (hifigan_pretrained.py:124) ----
     {
@@ -455,12 +524,12 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
             return ok;
         };
         int n_fused = 0;
+        bool pf = false;            // the fused pairs run on the persistent kernel (mrf_pair_f32_pf.h)
+        bool fused_sum = false;     // ... and the stage's last pair forms the MRF mean itself (no persistent summing launches)
         if (dtype == IRIS_HIFIGAN_F32 && use_mrf && !(stop.stage == (int)i && !(stop.step & 1))) {
             bool all_ok = true;
-            for (int m = 0; m < nd && all_ok; ++m) {
-                PairLaunchF32 pa; double f, wb;
-                all_ok = fill_pair(pa, m, f, wb) && pair_f32_applicable(pa, nk);
-            }
+            PairLaunchF32 pa0; double f0, wb0;
+            for (int m = 0; m < nd && all_ok; ++m) all_ok = fill_pair(pa0, m, f0, wb0) && pair_f32_applicable(pa0, nk);
             if (all_ok) {
                 bool sums = false;          // (the same decision as at the last step below)
                 if (use_sum && nk == 3) {
@@ -474,7 +543,22 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                         sums = mrf_kernel_applicable(b, nk) && !pq.zpar && !pq.small;
                     }
                 }
-                n_fused = sums ? nd - 1 : nd;
+                // The stage's LAST pair on the persistent summing kernel (mrf_pair_f32_pf.h: a block runs the three branches of
+                // its tile and stores only the MRF mean -- no xt, no per-branch outputs, one launch instead of the persistent
+                // kernel's two): taken where its whole-tile jobs fill at least four rounds of the chip well.  Measured
+                // (profiles/r03_notes.md): +3 % on the C = 32 stage and +0.6 % on the step at batch 32 x 500, neutral at
+                // batch 1 x 1000, a loss where a launch is one or two rounds (its jobs are 21 tap-units against 11 / 7 / 3).
+                // The non-summing pairs stay on the one-job-per-block kernel: as persistent, prefetching blocks they
+                // were 3-5 % slower at every size (diagnostic builds: IRIS_HIFIGAN_PAIR_PF_MODE=2).
+                const PairPfTileF32 pt = pair_pf_f32_tile(st.C);
+                const long long tiles_pf = (long long)((L_out + (pt.M - 10) - 1) / (pt.M - 10)) * B;
+                pf = IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_PF_MODE", 0) == 2 && pair_pf_f32_applicable(pa0, nk, false);
+                const int sum_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_SUM", 1);          // 0 never, 1 by size, 2 always
+                if (use_sum && sum_env && pair_pf_f32_applicable(pa0, nk, true)) {
+                    const PairPfPlanF32 sp = pair_pf_f32_plan(tiles_pf, device_cu_count(), pt.MINB, true);
+                    fused_sum = sum_env == 2 || (sp.efficiency >= 0.85 && tiles_pf >= 4LL * device_cu_count() * sp.per_cu);
+                }
+                n_fused = (fused_sum || !sums) ? nd : nd - 1;
             }
         }
         const float* cur_x[kMaxGroup];
@@ -483,16 +567,23 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
             if (m < n_fused) {
                 PairLaunchF32 pa; double flops, wbytes;
                 (void)fill_pair(pa, m, flops, wbytes);
-                const bool to_y = ((n_fused - 1 - m) & 1) == 0;
+                const bool is_sum = fused_sum && m == nd - 1;
+                // never in place: the running x of a branch alternates between its y and xt buffers, arranged so that the last
+                // fused pair ends in y -- or, in front of the summing pair (which writes the mean to y[0]), in xt
+                const bool to_y = fused_sum ? (((nd - 2 - m) & 1) != 0) : (((n_fused - 1 - m) & 1) == 0);
                 for (int j = 0; j < nk; ++j) { pa.p[j].x = cur_x[j]; pa.p[j].y = to_y ? ws + w.y[j] : ws + w.xt[j]; }
                 // algorithmic FLOP / bytes (accounting L) are those of both steps; the record carries the second step's index
                 TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 4.0 * n_el * nk * 5 + wbytes));
-                HIP_TRY(launch_pair_f32(pa, nk, stream));
+                // (a zeroed counter word per persistent launch: the upper half of the per-forward counters)
+                unsigned* const ctr = (pf_counters && IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_PF_DYN", 1)) ? h->tile_counters + kTileCounterWords / 2 + ((int)i * nd + m) : nullptr;
+                if (is_sum)  HIP_TRY(launch_pair_f32_pf(pa, nk, ws + w.y[0], ctr, stream));
+                else if (pf) HIP_TRY(launch_pair_f32_pf(pa, nk, nullptr, ctr, stream));
+                else         HIP_TRY(launch_pair_f32(pa, nk, stream));
                 TRY(prof.end());
                 for (int j = 0; j < nk; ++j) cur_x[j] = pa.p[j].y;
-                if (m == nd - 1) prev_summed = false;
+                if (m == nd - 1) prev_summed = is_sum;
                 if (stop.stage == (int)i && stop.step == 2 * m + 1) {
-                    if (until_flags) *until_flags = to_y ? 0 : IRIS_HIFIGAN_UNTIL_X_IN_XT;
+                    if (until_flags) *until_flags = is_sum ? IRIS_HIFIGAN_UNTIL_MEAN_IN_Y0 : (to_y ? 0 : IRIS_HIFIGAN_UNTIL_X_IN_XT);
                     TRY(prof.finish());
                     return IRIS_HIFIGAN_OK;
                 }
@@ -575,30 +666,102 @@ extern "C" {
 int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
                              void* wav_dev, void* workspace_dev, uint64_t workspace_bytes,
                              int32_t dtype, void* stream_) {
+    IRIS_ABI_BEGIN
     TRY(check_forward_args(h, mel_dev, B, T, workspace_dev, dtype));
     if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;  // empty batch / empty mel -> empty waveform
     if (!wav_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
+    TRY(ensure_prepared(h, dtype));
+    if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     const ForwardStop none{-1, -1};
-    if (dtype == IRIS_HIFIGAN_BF16)
-        return bf16_forward(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, (hipStream_t)stream_, none, nullptr);
-    return forward_f32(h, mel_dev, B, T, wav_dev, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, none, nullptr);
+    const int Bp = pass_items(B, T);
+    for (int b0 = 0; b0 < B; b0 += Bp) {
+        const int nb = B - b0 < Bp ? B - b0 : Bp;
+        const float* mel_p = (const float*)mel_dev + (size_t)b0 * h->cfg.in_channels * T;
+        float* wav_p = (float*)wav_dev + (size_t)b0 * h->hop * T;
+        if (dtype == IRIS_HIFIGAN_BF16)
+            TRY(bf16_forward(h, mel_p, nb, T, wav_p, workspace_dev, workspace_bytes, (hipStream_t)stream_, none, nullptr));
+        else
+            TRY(forward_f32(h, mel_p, nb, T, wav_p, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, none, nullptr));
+    }
+    return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t T,
                                    void* workspace_dev, uint64_t workspace_bytes, int32_t dtype,
                                    int32_t stop_stage, int32_t stop_step, int32_t* flags, void* stream_) {
+    IRIS_ABI_BEGIN
     TRY(check_forward_args(h, mel_dev, B, T, workspace_dev, dtype));
     if (B == 0 || T == 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "forward_until needs a non-empty input");
     if (stop_stage < 0 || stop_stage >= (int)h->stages.size() || stop_step < 0 || stop_step >= 2 * h->cfg.num_dilations[0])
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "no MRF step %d in stage %d", stop_step, stop_stage);
+    if (pass_items(B, T) != B)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "forward_until takes shapes that run in one pass (B * T <= %d frames)", kPassFrames);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
+    TRY(ensure_prepared(h, dtype));
+    if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     const ForwardStop stop{stop_stage, stop_step};
     if (dtype == IRIS_HIFIGAN_BF16)
         return bf16_forward(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream_, stop, flags);
     return forward_f32(h, mel_dev, B, T, nullptr, workspace_dev, workspace_bytes, dtype, (hipStream_t)stream_, stop, flags);
+    IRIS_ABI_END
+}
+
+int32_t iris_hifigan_describe_plan(const iris_hifigan_config* cfg, int32_t B, int32_t T, int32_t dtype, int32_t cu_count,
+                                   iris_hifigan_plan* out) {
+    IRIS_ABI_BEGIN
+    TRY(validate(cfg));
+    if (!out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "out is NULL");
+    memset(out, 0, sizeof(*out));
+    // a generator without a device: the layer table, the offsets of every weight packing and fake (never dereferenced)
+    // base pointers -- then the forward itself, with every launch recorded instead of issued
+    iris_hifigan_handle h;
+    h.cfg = *cfg;
+    h.host_only = true;
+    build_layers(&h);
+    h.blob = reinterpret_cast<float*>((uintptr_t)0x10000000);
+    h.tile_counters = reinterpret_cast<unsigned*>((uintptr_t)0x08000000);
+    if (assign_w16_offsets(&h) > 0) h.blob_w16 = reinterpret_cast<float*>((uintptr_t)0x18000000);
+    h.tried_w16 = true;
+    TRY(bf16_build_blob(&h, nullptr)); h.tried_bf16 = true;
+    TRY(f32s_build_blob(&h, nullptr)); h.tried_s3 = true;
+    void* const mel = reinterpret_cast<void*>((uintptr_t)0x40000000);
+    void* const wav = reinterpret_cast<void*>((uintptr_t)0x50000000);
+    void* const ws = reinterpret_cast<void*>((uintptr_t)0x100000000ull);
+    TRY(check_forward_args(&h, mel, B, T, ws, dtype));
+    if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h.blob_s3)
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
+    uint64_t need = 0;
+    TRY(iris_hifigan_workspace_bytes(&h, B, T, dtype, &need));
+    out->workspace_bytes = need;
+    out->cu_count = cu_count > 0 ? cu_count : 256;
+    if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;
+    DryRunLaunch recs[IRIS_HIFIGAN_MAX_PLAN_LAUNCHES];
+    DryRun dry{recs, IRIS_HIFIGAN_MAX_PLAN_LAUNCHES, 0, out->cu_count};
+    struct Scope { DryRun* prev; Scope(DryRun* d) : prev(dry_run_slot()) { dry_run_slot() = d; } ~Scope() { dry_run_slot() = prev; } } scope(&dry);
+    const ForwardStop none{-1, -1};
+    int rc = IRIS_HIFIGAN_OK;
+    const int Bp = pass_items(B, T);
+    out->passes = (B + Bp - 1) / Bp;
+    for (int b0 = 0; b0 < B && rc == IRIS_HIFIGAN_OK; b0 += Bp) {          // (the launches of every pass are recorded)
+        const int nb = B - b0 < Bp ? B - b0 : Bp;
+        rc = dtype == IRIS_HIFIGAN_BF16 ? bf16_forward(&h, mel, nb, T, wav, ws, need, nullptr, none, nullptr)
+                                        : forward_f32(&h, mel, nb, T, wav, ws, need, dtype, nullptr, none, nullptr);
+    }
+    out->n_launches = dry.n;
+    for (int i = 0; i < dry.n && i < IRIS_HIFIGAN_MAX_PLAN_LAUNCHES; ++i) {
+        iris_hifigan_plan_launch& o = out->launches[i];
+        strncpy(o.kernel, recs[i].kernel ? recs[i].kernel : "", sizeof(o.kernel) - 1);
+        o.grid[0] = recs[i].grid[0]; o.grid[1] = recs[i].grid[1]; o.grid[2] = recs[i].grid[2];
+        o.block = recs[i].block; o.lds_bytes = recs[i].lds_bytes;
+    }
+    return rc;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, int32_t T, int32_t dtype,
@@ -606,6 +769,7 @@ int32_t iris_hifigan_workspace_layout(const iris_hifigan_handle* h, int32_t B, i
     if (!h || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     memset(out, 0, sizeof(*out));
+    B = pass_items(B, T);                                   // (the layout of one pass; forward_until takes single-pass shapes only)
     if (dtype == IRIS_HIFIGAN_BF16) return bf16_workspace_map(h, B, T, out);
     if (dtype != IRIS_HIFIGAN_F32 && dtype != IRIS_HIFIGAN_F32_SPLIT)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
@@ -635,6 +799,7 @@ int32_t iris_hifigan_op_conv1d(const float* x_dev, const float* w_host, const fl
                                const float* res_dev, float* y_dev, int32_t B, int32_t L,
                                int32_t C_in, int32_t C_out, int32_t k, int32_t dilation,
                                int32_t in_act, float slope, int32_t x_channels_first, void* stream_) {
+    IRIS_ABI_BEGIN
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || k < 1 || !(k & 1) || dilation < 1 || B > 65535)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv1d shape");
@@ -653,12 +818,14 @@ int32_t iris_hifigan_op_conv1d(const float* x_dev, const float* w_host, const fl
     HIP_TRY(launch_conv(a, 1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_conv_transpose1d(const float* x_dev, const float* w_host,
                                          const float* bias_host, float* y_dev, int32_t B, int32_t L,
                                          int32_t C_in, int32_t C_out, int32_t k, int32_t u,
                                          int32_t in_act, float slope, void* stream_) {
+    IRIS_ABI_BEGIN
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || u < 1 || k < u || ((k - u) & 1) || B > 65535 || u > 65535)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_transpose1d shape");
@@ -681,12 +848,14 @@ int32_t iris_hifigan_op_conv_transpose1d(const float* x_dev, const float* w_host
     HIP_TRY(launch_conv(a, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, const float* x2_dev,
                                   const float* w_host, const float* bias_host, float* y_dev,
                                   int32_t B, int32_t L, int32_t C_in, int32_t k, float slope,
                                   void* stream_) {
+    IRIS_ABI_BEGIN
     if (!x0_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C_in < 1 || k < 1 || !(k & 1) || B > 65535)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad conv_post shape");
@@ -707,12 +876,14 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
     HIP_TRY(post::launch_conv_post(a, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* w_host, const float* const* bias_host,
                                  const float* const* res_dev, float* const* y_dev, float* mean_dev,
                                  int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
                                  float slope, int32_t plan, void* stream_) {
+    IRIS_ABI_BEGIN
     if (!x_dev || !w_host || !bias_host || !k || !dil || (!y_dev && !mean_dev))
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 4) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
@@ -756,21 +927,24 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
     HIP_TRY(launch_mrf_conv(a, nk, stream, force));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* w1_host, const float* const* b1_host,
                                  const float* const* w2_host, const float* const* b2_host, float* const* y_dev,
-                                 int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
-                                 float slope, void* stream_) {
-    if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || !y_dev || !k || !dil)
+                                 float* mean_dev, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                 float slope, int32_t mode, void* stream_) {
+    IRIS_ABI_BEGIN
+    if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || (!y_dev && !mean_dev) || !k || !dil)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
-    if (B < 1 || L < 1 || C < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_pair shape");
+    if (B < 1 || L < 1 || C < 1 || mode < 0 || mode > 2) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_pair shape or mode");
+    if (mean_dev && mode == 0) return fail(IRIS_HIFIGAN_UNSUPPORTED, "only the persistent kernel (modes 1, 2) forms the mean");
     const int nk = 3;
     hipStream_t stream = (hipStream_t)stream_;
     DevBuf wb[3];
     PairLaunchF32 pa; memset(&pa, 0, sizeof(pa));
     for (int j = 0; j < nk; ++j) {
-        if (!x_dev[j] || !w1_host[j] || !b1_host[j] || !w2_host[j] || !b2_host[j] || !y_dev[j])
+        if (!x_dev[j] || !w1_host[j] || !b1_host[j] || !w2_host[j] || !b2_host[j] || (!mean_dev && !y_dev[j]))
             return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
         if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad branch kernel size / dilation");
         const size_t wf = packed_conv1d_floats(C, C, k[j]), cpad = ((size_t)C + 3) & ~(size_t)3;
@@ -781,16 +955,28 @@ int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* 
         memcpy(packed.data() + 2 * wf + cpad, b2_host[j], sizeof(float) * C);
         HIP_TRY(wb[j].upload(packed));
         PairProblemF32& p = pa.p[j];
-        p.x = x_dev[j]; p.y = y_dev[j];
+        p.x = x_dev[j]; p.y = mean_dev ? mean_dev : y_dev[j];      // (summing launch: the branch outputs are never written)
         p.w1 = (const f32x4*)wb[j].p; p.w2 = (const f32x4*)(wb[j].p + wf);
         p.b1 = wb[j].p + 2 * wf; p.b2 = wb[j].p + 2 * wf + cpad;
         p.ks = k[j]; p.dil = dil[j];
     }
     pa.B = B; pa.L = L; pa.C = C; pa.slope = slope;
     if (!pair_f32_applicable(pa, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the fused fp32 pair kernel");
-    HIP_TRY(launch_pair_f32(pa, nk, stream));
+    if (mode == 1 || mode == 2) {
+        if (!pair_pf_f32_applicable(pa, nk, mean_dev != nullptr)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the persistent pair kernel");
+        struct Word { unsigned* p = nullptr; ~Word() { if (p) (void)hipFree(p); } } ctr;
+        if (mode == 1) {                                    // blocks draw their jobs from a counter (mode 2: fixed stride)
+            HIP_TRY(hipMalloc(&ctr.p, sizeof(unsigned)));
+            HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(unsigned), stream));
+        }
+        HIP_TRY(launch_pair_f32_pf(pa, nk, mean_dev, ctr.p, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+        HIP_TRY(launch_pair_f32(pa, nk, stream));
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,6 +996,7 @@ extern "C" {
 
 int32_t iris_postnet_create(int32_t n_mels, int32_t num_layers, int32_t channels, int32_t kernel_size,
                             const float* weights_host, uint64_t n_weights, iris_postnet_handle** out) {
+    IRIS_ABI_BEGIN
     if (!weights_host || !out) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (n_mels < 1 || channels < 1 || num_layers < 2 || num_layers > 64 || kernel_size < 1 || !(kernel_size & 1))
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "PostNet needs n_mels, channels >= 1, 2 <= num_layers <= 64, odd kernel_size");
@@ -854,6 +1041,7 @@ int32_t iris_postnet_create(int32_t n_mels, int32_t num_layers, int32_t channels
     }
     *out = h;
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_postnet_destroy(iris_postnet_handle* h) {
@@ -875,6 +1063,7 @@ int32_t iris_postnet_workspace_bytes(const iris_postnet_handle* h, int32_t B, in
 
 int32_t iris_postnet_forward(iris_postnet_handle* h, const void* mel_dev, int32_t B, int32_t T,
                              void* out_dev, void* workspace_dev, uint64_t workspace_bytes, void* stream_) {
+    IRIS_ABI_BEGIN
     if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
     if (B < 0 || T < 0) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "negative shape");
     if (B == 0 || T == 0) return IRIS_HIFIGAN_OK;
@@ -908,10 +1097,10 @@ int32_t iris_postnet_forward(iris_postnet_handle* h, const void* mel_dev, int32_
         x = a.p[0].y;
     }
     dim3 grid((unsigned)((T + 255) / 256), (unsigned)B), block(256);
-    hipLaunchKernelGGL(postnet_residual_kernel, grid, block, 0, stream, (const float*)mel_dev, (const float*)res,
-                       (float*)out_dev, h->n_mels, T);                  // x + res (postnet.py:67)
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_kernel(postnet_residual_kernel, grid, block, 0, stream, (const float*)mel_dev, (const float*)res,
+                          (float*)out_dev, h->n_mels, T));              // x + res (postnet.py:67)
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 }  // extern "C"

@@ -7,6 +7,9 @@
 #include "generator_internal.h"
 #include "conv_mfma_bf16.h"
 #include "mrf_pair_bf16.h"
+#ifdef IRIS_MRF_DIAG
+#include "mrf_pair_bf16_pf.h"   // round-3 experiment (persistent + prefetching pair): measured slower, diagnostic builds only
+#endif
 #include "conv_mfma_f32s.h"
 #include "conv_post.h"
 
@@ -59,6 +62,7 @@ int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host) {
         off += (l.w16_halfs + 127) & ~(size_t)127;
     });
     h->blob16_halfs = off;
+    if (h->host_only) { h->blob16 = reinterpret_cast<uint16_t*>((uintptr_t)0x20000000); return IRIS_HIFIGAN_OK; }   // offsets only
     std::vector<uint16_t> host(off, 0);
     const float* src = weights_host;
     for_each_layer(h, [&](ConvLayer& l) {
@@ -94,6 +98,7 @@ int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host) {
                     off += (2 * s3::packed_plane_halfs(l.C_in, l.C_out, l.k) + 127) & ~(size_t)127;
                 }
     }
+    if (h->host_only) { h->blob_s3 = reinterpret_cast<uint16_t*>((uintptr_t)0x30000000); return IRIS_HIFIGAN_OK; }   // offsets only
     std::vector<uint16_t> host(off, 0);
     const float* src = weights_host;
     for_each_layer(h, [&](ConvLayer& l) {
@@ -180,6 +185,13 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                  int32_t* until_flags) {
     if (!h->blob16)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 path needs channel counts that are multiples of 8 and at most %d MRF kernels", kMaxGroup);
+    {   // the bf16 kernels address one batch item's tensor with 32-bit byte offsets and have no wider fallback
+        double per_item = (double)T * h->pre.C_out, L = T;
+        for (const auto& st : h->stages) { L *= st.rate; if (L * st.C > per_item) per_item = L * st.C; }
+        if (per_item * 2.0 >= 2147483648.0)
+            return fail(IRIS_HIFIGAN_UNSUPPORTED, "bf16 path: %d frames make a single item's activations 2^31 bytes or more; "
+                        "split the utterance (iris.streaming) or use fp32", T);
+    }
     const Ws16 w = ws16_layout(h, B, T);
     if (workspace_bytes < w.total * sizeof(uint16_t))
         return fail(IRIS_HIFIGAN_WORKSPACE_TOO_SMALL, "workspace has %llu bytes, need %llu",
@@ -273,6 +285,10 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 for (int j = 0; j < nk; ++j) same_k = same_k && st.c1[j][m].k == st.c2[j][m].k && st.c2[j][m].dil == 1;
                 if (!want_xt && same_k && pair_applicable(pa, nk)) {
                     TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
+#ifdef IRIS_MRF_DIAG
+                    if (pair_pf_applicable(pa, nk)) HIP_TRY(launch_pair_bf16_pf(pa, nk, stream));
+                    else
+#endif
                     HIP_TRY(launch_pair_bf16(pa, nk, stream));
                     TRY(prof.end());
                     for (int j = 0; j < nk; ++j) cur[j] = pa.p[j].y;
@@ -318,14 +334,15 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         TRY(prof.begin(3, -1, 0, 2.0 * fB * L * l.C_in * l.k,
                        2.0 * fB * L * l.C_in * nk + 4.0 * (fB * L + (double)l.ref_w_floats + 1)));
         const int C = l.C_in;
-        if (C == 8 || C == 16 || C == 32 || C == 64) {
-            // 16-byte staging, batch folded into the grid (conv_post.h); same arithmetic as the kernel below
-            post::ConvPostLaunch a; memset(&a, 0, sizeof(a));
-            for (int j = 0; j < nk; ++j) a.x[j] = cur[j];
-            a.n_in = nk; a.inv_n = 1.0f / (float)nk;
-            a.w = blob + l.w_off; a.bias = blob + l.b_off; a.y = (float*)wav_dev;
-            a.B = B; a.L = L; a.C = C; a.k = l.k; a.slope = slope;
-            HIP_TRY(post::launch_conv_post_t<true>(a, stream));
+        post::ConvPostLaunch ar; memset(&ar, 0, sizeof(ar));
+        for (int j = 0; j < nk && j < 4; ++j) ar.x[j] = cur[j];
+        ar.n_in = nk; ar.inv_n = 1.0f / (float)nk;
+        ar.w = blob + l.w_off; ar.bias = blob + l.b_off; ar.y = (float*)wav_dev;
+        ar.B = B; ar.L = L; ar.C = C; ar.k = l.k; ar.slope = slope;
+        if (post::conv_post_rows_ok(ar, true)) {
+            // 16-byte staging, batch folded into the grid (conv_post.h); same arithmetic as the kernel below, which takes
+            // the shapes this one cannot (other channel counts; a single item of 2^31 bytes or more)
+            HIP_TRY(post::launch_conv_post_t<true>(ar, stream));
         } else {
             PostLaunch a; memset(&a, 0, sizeof(a));
             for (int j = 0; j < nk; ++j) a.x[j] = cur[j];
@@ -363,6 +380,7 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
                                     const void* res_dev, void* y_dev, int32_t B, int32_t L, int32_t C_in,
                                     int32_t C_out, int32_t k, int32_t dilation, int32_t in_act, float slope,
                                     void* stream_) {
+    IRIS_ABI_BEGIN
     using namespace iris;
     using namespace iris::b16;
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
@@ -384,12 +402,14 @@ int32_t iris_hifigan_op_conv1d_bf16(const void* x_dev, const float* w_host, cons
     HIP_TRY(launch_conv_bf16(a, 1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
                                       const float* const* w2_host, const float* const* b2_host, void* const* y_dev,
                                       int32_t n_branches, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
                                       float slope, void* stream_) {
+    IRIS_ABI_BEGIN
     using namespace iris;
     using namespace iris::b16;
     if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || !y_dev || !k || !dil)
@@ -420,14 +440,20 @@ int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* con
         a.p[j].w1 = w1b[j].p; a.p[j].w2 = w2b[j].p;
         a.p[j].b1 = (const float*)b1b[j].p; a.p[j].b2 = (const float*)b2b[j].p;
     }
+#ifdef IRIS_MRF_DIAG
+    if (pair_pf_applicable(a, n_branches)) HIP_TRY(launch_pair_bf16_pf(a, n_branches, stream));
+    else
+#endif
     HIP_TRY(launch_pair_bf16(a, n_branches, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,
                                     float* y_dev, int32_t B, int32_t L, int32_t C, int32_t k, int32_t dilation, float slope,
                                     void* stream_) {
+    IRIS_ABI_BEGIN
     using namespace iris;
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C < 1 || k < 1 || !(k & 1) || dilation < 1 || B > 65535)
@@ -446,11 +472,13 @@ int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, con
     HIP_TRY(s3::launch(a, 1, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_conv_transpose1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, float* y_dev,
                                               int32_t B, int32_t L, int32_t C_in, int32_t C_out, int32_t k, int32_t u,
                                               float slope, void* stream_) {
+    IRIS_ABI_BEGIN
     using namespace iris;
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
     if (B < 1 || L < 1 || C_in < 1 || C_out < 1 || u < 1 || k < u || ((k - u) & 1) || B > 65535 || u > 65535)
@@ -469,11 +497,13 @@ int32_t iris_hifigan_op_conv_transpose1d_f32s(const float* x_dev, const float* w
     HIP_TRY(s3::launch(a, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_host, const float* bias_host,
                                               void* y_dev, int32_t B, int32_t L, int32_t C_in, int32_t C_out,
                                               int32_t k, int32_t u, int32_t in_act, float slope, void* stream_) {
+    IRIS_ABI_BEGIN
     using namespace iris;
     using namespace iris::b16;
     if (!x_dev || !w_host || !bias_host || !y_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
@@ -499,6 +529,7 @@ int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_
     HIP_TRY(launch_conv_bf16(a, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
 }
 
 }  // extern "C"

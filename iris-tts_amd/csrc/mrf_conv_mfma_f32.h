@@ -93,6 +93,12 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     constexpr int ablate = 0;
 #endif
     const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
+#ifdef IRIS_MRF_DIAG
+    // A/B (profiles/r03_notes.md): the two blocks of a CU run the same equal-cost sequence and would stay in lock-step; delay
+    // the second residency generation by a.stagger x 1,024 cycles
+    if (a.stagger > 0 && a.stagger_mod > 0 && (((int)blockIdx.x / a.stagger_mod) & 1))
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
 
     // A tile = (batch item, time tile, C_out block).  Everything a phase needs to know about it:
     struct Tile {
@@ -607,6 +613,8 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     a.nz_serial = nz;
     a.nz = 1;
     a.ablate = IRIS_DIAG_ENV("IRIS_HIFIGAN_ABLATE", 0);
+    a.stagger = IRIS_DIAG_ENV("IRIS_HIFIGAN_STAGGER", 0);
+    a.stagger_mod = mrf_cu_count();
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
     if (pl.small) return launch_mrf_small(a, nz, stream);
     const int T_BLK = t.WT * pl.MT * 32;
@@ -621,13 +629,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
 #define IRIS_MRF_LAUNCH_K(...)                                                                    \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
-        if (lds_bytes > 64 * 1024) {                                                              \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                               (int)lds_bytes);                                   \
-            if (e != hipSuccess) return e;                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                               \
+        { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
     } while (0)
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
     do {                                                                                          \
@@ -664,7 +666,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
 #endif
 #undef IRIS_MRF_LAUNCH_DB
 #undef IRIS_MRF_LAUNCH_K
-    return hipGetLastError();
+    return hipSuccess;       // (every launch above has reported its own status)
 }
 
 }  // namespace iris

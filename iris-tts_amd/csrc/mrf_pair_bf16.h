@@ -52,6 +52,7 @@ struct PairLaunch {
     int Qp, n_ct;         // packed-weight geometry (packed_qsteps / packed_cotiles of C)
     int n_jobs;           // tiles x branches (tiles = ceil(L / smallest T_OUT))
     int jobs_per_xcd;     // ceil(n_jobs / 8)
+    int bias_off;         // persistent kernel: byte offset of the bias table in LDS
     int ablate;           // diagnostics only: 1 no staging loads, 2 no MFMA loops, 4 no stores, 8 no residual loads
     unsigned long long* dbg;  // diagnostics only (stamp builds): per-segment cycle sums, else nullptr
 };
@@ -343,11 +344,15 @@ struct PairTile { int WT, WC, MT, NT, MINB, M; };
 
 inline bool pair_tile_for(int C, PairTile* t) {
     const int v64 = IRIS_DIAG_ENV("IRIS_B16_PAIR64", 0);
-    if (C == 32) { *t = PairTile{4, 1, 3, 1, 4, 384}; return true; }   // (512 rows at three blocks per CU: no difference)
+    if (C == 32) {                                                     // (512 rows at three blocks per CU: no difference)
+        *t = IRIS_DIAG_ENV("IRIS_B16_PAIR32", 0) == 1 ? PairTile{4, 1, 3, 1, 3, 384} : PairTile{4, 1, 3, 1, 4, 384};   // (A/B: three blocks per CU)
+        return true;
+    }
     if (C == 64) {
         // 256 rows as 2 x 2 waves of 128 x 32 at three blocks per CU: 2 % ahead of 192 rows at four (2.09 vs 2.13 ms)
         if (v64 == 1) { *t = PairTile{4, 1, 2, 2, 3, 256}; return true; }
         if (v64 == 2) { *t = PairTile{2, 2, 3, 1, 4, 192}; return true; }
+        if (v64 == 3) { *t = PairTile{2, 2, 4, 1, 2, 256}; return true; }   // (A/B: the default tile at two blocks per CU)
         *t = PairTile{2, 2, 4, 1, 3, 256};
         return true;
     }
@@ -421,20 +426,17 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
     dim3 grid((unsigned)(a.jobs_per_xcd * 8), (unsigned)a.B, 1u), block(256);
 #define IRIS_PAIR_CASE(WT_, WC_, MT_, NT_, C_, MINB_)                                                        \
-    if (a.C == C_ && t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_) {                            \
+    if (a.C == C_ && t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.MINB == MINB_) {        \
         auto kfn = mrf_pair_bf16_kernel<WT_, WC_, MT_, NT_, C_, MINB_>;                                      \
-        if (lds_bytes > 64 * 1024) {                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            if (e != hipSuccess) return e;                                                                   \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                                          \
-        return hipGetLastError();                                                                            \
+        { const hipError_t e__ = ::iris::launch_kernel_named("mrf_pair_bf16_kernel", kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+        return hipSuccess;                                                                                   \
     }
     IRIS_PAIR_CASE(4, 1, 3, 1, 32, 4)
+    IRIS_PAIR_CASE(4, 1, 3, 1, 32, 3)
     IRIS_PAIR_CASE(2, 2, 3, 1, 64, 4)
     IRIS_PAIR_CASE(4, 1, 2, 2, 64, 3)
     IRIS_PAIR_CASE(2, 2, 4, 1, 64, 3)
+    IRIS_PAIR_CASE(2, 2, 4, 1, 64, 2)
     IRIS_PAIR_CASE(2, 2, 2, 2, 128, 3)
     IRIS_PAIR_CASE(2, 2, 3, 2, 128, 2)
 #undef IRIS_PAIR_CASE

@@ -323,13 +323,8 @@ inline hipError_t launch_pair_f32(PairLaunchF32& a, int nz, hipStream_t stream) 
 #define IRIS_PAIR_F32_CASE(WT_, WC_, MT_, C_, MINB_)                                                         \
     if (a.C == C_ && t.WT == WT_ && t.MT == MT_) {                                                           \
         auto kfn = mrf_pair_f32_kernel<WT_, WC_, MT_, C_, MINB_>;                                            \
-        if (lds_bytes > 64 * 1024) {                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            if (e != hipSuccess) return e;                                                                   \
-        }                                                                                                    \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, stream, a);                                          \
-        return hipGetLastError();                                                                            \
+        { const hipError_t e__ = ::iris::launch_kernel_named("mrf_pair_f32_kernel", kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+        return hipSuccess;                                                                                   \
     }
     IRIS_PAIR_F32_CASE(4, 1, 1, 32, 4)
     IRIS_PAIR_F32_CASE(2, 2, 2, 64, 3)

@@ -209,8 +209,7 @@ inline hipError_t launch_mrf_small(ConvLaunch& a, int nz, hipStream_t stream) {
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)(kSmallRows + span) * (kSmallCic + 4) * sizeof(float);
     dim3 grid((unsigned)blocks, (unsigned)a.B), block(256);
-    hipLaunchKernelGGL(mrf_small_f32_kernel, grid, block, lds_bytes, stream, a);
-    return hipGetLastError();
+    return ::iris::launch_kernel(mrf_small_f32_kernel, grid, block, lds_bytes, stream, a);
 }
 
 }  // namespace iris

@@ -158,8 +158,8 @@ class GeneratorEngine:
             ws_ptr = self._workspace.data_ptr()
             static_in.copy_(mel)
             was_profiling = self._profiling
-            if was_profiling:
-                self.set_profiling(False)        # no event records inside a capture
+            if was_profiling:                    # no event records inside a capture; the records collected so far are kept
+                _native.check("iris_hifigan_pause_profiling", self.lib.iris_hifigan_pause_profiling(self._handle, 1))
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                                # warm-up outside capture
@@ -171,7 +171,7 @@ class GeneratorEngine:
             entry = (graph, static_in, static_out, ws_ptr)
             self._graphs[key] = entry
             if was_profiling:
-                self.set_profiling(was_profiling)
+                _native.check("iris_hifigan_pause_profiling", self.lib.iris_hifigan_pause_profiling(self._handle, 0))
         graph, static_in, static_out, ws_ptr = entry
         if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
             # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
@@ -180,6 +180,12 @@ class GeneratorEngine:
         static_in.copy_(mel.to(device=self.device, dtype=torch.float32))
         graph.replay()
         return static_out
+
+    def prepare(self, dtype: Optional[str] = None) -> None:
+        """Builds the weight packing ``dtype`` needs now (otherwise the first forward of the dtype does, synchronously)."""
+        code = _dtype_code(dtype or self.default_dtype)
+        with torch.cuda.device(self.device):
+            _native.check("iris_hifigan_prepare", self.lib.iris_hifigan_prepare(self._handle, code))
 
     # -- profiling (bench.py roofline leg) -----------------------------------------------------
     def set_profiling(self, enabled) -> None:

@@ -14,7 +14,8 @@ from typing import Optional
 MAX_STAGES = 8
 MAX_KERNELS = 8
 MAX_DILATIONS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_PLAN_LAUNCHES = 96
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
@@ -84,6 +85,30 @@ class WorkspaceMap(ctypes.Structure):
     ]
 
 
+class PlanLaunch(ctypes.Structure):
+    """``iris_hifigan_plan_launch``"""
+
+    _fields_ = [
+        ("kernel", ctypes.c_char * 80),
+        ("grid", ctypes.c_uint32 * 3),
+        ("block", ctypes.c_uint32),
+        ("lds_bytes", ctypes.c_uint64),
+    ]
+
+
+class Plan(ctypes.Structure):
+    """``iris_hifigan_plan``"""
+
+    _fields_ = [
+        ("workspace_bytes", ctypes.c_uint64),
+        ("n_launches", ctypes.c_int32),
+        ("cu_count", ctypes.c_int32),
+        ("passes", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("launches", PlanLaunch * MAX_PLAN_LAUNCHES),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/iris_hifigan.h
 _c = ctypes
 _vp, _i32, _u64, _f = _c.c_void_p, _c.c_int32, _c.c_uint64, _c.c_float
@@ -94,6 +119,9 @@ SYMBOLS = {
     "iris_hifigan_weight_count": (_i32, [_c.POINTER(Config), _c.POINTER(_u64)]),
     "iris_hifigan_create": (_i32, [_c.POINTER(Config), _fp, _u64, _c.POINTER(_vp)]),
     "iris_hifigan_destroy": (_i32, [_vp]),
+    "iris_hifigan_prepare": (_i32, [_vp, _i32]),
+    "iris_hifigan_pause_profiling": (_i32, [_vp, _i32]),
+    "iris_hifigan_describe_plan": (_i32, [_c.POINTER(Config), _i32, _i32, _i32, _i32, _c.POINTER(Plan)]),
     "iris_hifigan_workspace_bytes": (_i32, [_vp, _i32, _i32, _i32, _c.POINTER(_u64)]),
     "iris_hifigan_forward": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _i32, _vp]),
     "iris_hifigan_workspace_layout": (_i32, [_vp, _i32, _i32, _i32, _c.POINTER(WorkspaceMap)]),
@@ -107,7 +135,7 @@ SYMBOLS = {
     "iris_hifigan_op_mrf_step": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_vp), _c.POINTER(_vp), _vp,
                                        _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _i32, _vp]),
     "iris_hifigan_op_mrf_pair": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
-                                       _c.POINTER(_vp), _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
+                                       _c.POINTER(_vp), _vp, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _i32, _vp]),
     "iris_hifigan_op_mrf_pair_bf16": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
                                             _c.POINTER(_vp), _i32, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
     "iris_hifigan_op_conv1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
@@ -163,6 +191,21 @@ def check(fn_name: str, status: int) -> None:
     if status != 0:
         msg = load().iris_hifigan_last_error()
         raise NativeCallError(fn_name, status, msg.decode("utf-8", "replace") if msg else "")
+
+
+def describe_plan(cfg, batch: int, frames: int, dtype_code: int = DTYPE_F32, cu_count: int = 0) -> dict:
+    """Launch plan of one forward, computed on the host alone (``iris_hifigan_describe_plan``: no device needed,
+    nothing is launched): workspace bytes and, per launch, kernel name, grid, block and dynamic LDS."""
+    lib = load()
+    plan = Plan()
+    ccfg = make_config(cfg)
+    check("iris_hifigan_describe_plan", lib.iris_hifigan_describe_plan(ctypes.byref(ccfg), batch, frames, dtype_code, cu_count,
+                                                                       ctypes.byref(plan)))
+    n = min(plan.n_launches, MAX_PLAN_LAUNCHES)
+    return {"workspace_bytes": int(plan.workspace_bytes), "n_launches": int(plan.n_launches), "cu_count": int(plan.cu_count),
+            "passes": int(plan.passes),
+            "launches": [{"kernel": plan.launches[i].kernel.decode(), "grid": tuple(plan.launches[i].grid),
+                          "block": int(plan.launches[i].block), "lds_bytes": int(plan.launches[i].lds_bytes)} for i in range(n)]}
 
 
 def make_config(cfg) -> Config:

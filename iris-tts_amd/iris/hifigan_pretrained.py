@@ -155,11 +155,21 @@ class HiFiGANModel(nn.Module):
         through ``p.numpy()`` -- must be followed by ``invalidate()``, or the GPU keeps running the old weights."""
         self._drop_engine()
 
+    @staticmethod
+    def _version_of(t):
+        """A tensor's in-place version counter, or None for tensors that have none (created under
+        ``torch.inference_mode()``: reading ``_version`` raises there).  Untracked tensors repack only on
+        ``invalidate()`` / ``load_state_dict``."""
+        try:
+            return t._version
+        except RuntimeError:
+            return None
+
     def _parameter_versions(self):
         tensors = self.__dict__.get("_packed_from")
         if tensors is None:
             return None
-        return tuple(t._version for t in tensors)
+        return tuple(self._version_of(t) for t in tensors)
 
     def engine(self) -> GeneratorEngine:
         if self._engine is not None and self._parameter_versions() != self.__dict__.get("_packed_versions"):
@@ -171,7 +181,7 @@ class HiFiGANModel(nn.Module):
             sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
             self._engine = GeneratorEngine(self.config, sd, device)
             self.__dict__["_packed_from"] = tensors
-            self.__dict__["_packed_versions"] = tuple(t._version for t in tensors)
+            self.__dict__["_packed_versions"] = tuple(self._version_of(t) for t in tensors)
         return self._engine
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

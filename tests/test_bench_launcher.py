@@ -41,6 +41,12 @@ def test_self_launch_shards_the_global_batch(world, global_batch, extras):
     assert line["stub"] is True and "NOT a measurement" in line["data"]
     # value = whole-job samples per second: global batch x frames x hop x steps / max-over-ranks time
     assert line["value"] == pytest.approx(global_batch * 12 * 256 / (line["ms_per_step"] * 1e-3), rel=1e-9)
+    # the line is self-verifying: what the process group itself reported, the collective on its own, every rank's clock
+    coll = line["collective"]
+    assert coll["backend"] == "gloo" and coll["world_size"] == world and coll["timed_gathers"] == 10
+    assert coll["bytes_per_rank"] == -(-global_batch // world) * 12 * 256 * 4
+    assert coll["bytes_gathered_per_rank"] == global_batch * 12 * 256 * 4 and coll["gather_only_ms"] > 0
+    assert len(line["per_rank_ms"]) == world and max(line["per_rank_ms"]) == pytest.approx(line["ms_per_step"], rel=1e-6)
     if extras:
         assert [g["frames"] for g in line["grid"]] == [100, 500, 1000]
         assert all(g["global_batch"] == global_batch and g["samples_per_s"] > 0 for g in line["grid"])

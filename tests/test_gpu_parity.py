@@ -214,12 +214,16 @@ def test_mrf_summing_step_matches_oracle(lib, B, L, C, plan):
     assert np.array_equal(got, ((sep[0] + sep[1]) + sep[2]) / np.float32(3))
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,L,C,dils", [(1, 700, 32, (1, 1, 1)), (2, 333, 32, (5, 5, 5)), (1, 520, 64, (3, 3, 3)), (3, 190, 64, (5, 5, 5)),
-                                        (1, 5, 32, (3, 3, 3)), (2, 11000, 64, (3, 3, 3))])   # (the last one: 128-row tiles at C = 64)
-def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils):
-    """The fused fp32 conv pair (csrc/mrf_pair_f32.h: conv1 -> xt in LDS -> conv2 + residual, C = 32 / 64) against the numpy
-    oracle's ResBlock arithmetic (hifigan_pretrained.py:64-71), and bit for bit against the two separate launches of the
-    persistent kernel it replaces -- several tiles per branch, ragged lengths, a length shorter than the kernel."""
+                                        (1, 5, 32, (3, 3, 3)), (2, 11000, 64, (3, 3, 3)),    # (128-row tiles at C = 64)
+                                        (5, 30000, 32, (3, 3, 3))])   # 3,810 jobs: persistent blocks walk several jobs each
+def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils, mode):
+    """The fused fp32 conv pair (csrc/mrf_pair_f32.h, mode 0; its persistent, prefetching form csrc/mrf_pair_f32_pf.h, modes 1 / 2 = jobs drawn from a
+    counter / fixed stride:
+    conv1 -> xt in LDS -> conv2 + residual, C = 32 / 64) against the numpy oracle's ResBlock arithmetic
+    (hifigan_pretrained.py:64-71), and bit for bit against the two separate launches of the persistent kernel it replaces --
+    several tiles per branch, ragged lengths, a length shorter than the kernel, more jobs than block slots."""
     rng = np.random.default_rng(C * 11 + L)
     ks = (3, 7, 11)
     xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
@@ -230,25 +234,39 @@ def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils):
     xd = [_cl(x) for x in xs]
     yd = [torch.full((B, L, C), float("nan"), device="cuda") for _ in range(3)]
     vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
-    _check("op_mrf_pair", lib.iris_hifigan_op_mrf_pair(
-        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
-        fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]), vp3(*[t.data_ptr() for t in yd]),
-        B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None))
+
+    def pair(y_tensors, mean_tensor, m):
+        return lib.iris_hifigan_op_mrf_pair(
+            vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
+            fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]),
+            vp3(*[t.data_ptr() for t in y_tensors]) if y_tensors is not None else None,
+            ctypes.c_void_p(mean_tensor.data_ptr()) if mean_tensor is not None else None,
+            B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, m, None)
+
+    _check("op_mrf_pair", pair(yd, None, mode))
     got = [t.cpu().numpy().transpose(0, 2, 1) for t in yd]
     _, xt = _mrf_step(lib, xs, w1, b1, None, B, L, C, dils, 0, mean=False)
     _, sep = _mrf_step(lib, xt, w2, b2, xs, B, L, C, (1, 1, 1), 0, mean=False)
+    small = B * L * C <= 400_000                         # (the numpy oracle is slow: large cases are checked bit for bit only)
     for j in range(3):
-        want_xt = orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), w1[j], b1[j], dils[j]).astype(np.float32)
-        want = orc.conv1d_np(orc.lrelu_np(want_xt, 0.1), w2[j], b2[j], 1) + xs[j]
         assert np.isfinite(got[j]).all()
-        assert np.abs(got[j] - want).max() <= 2 * TOL_LAYER * max(1.0, np.abs(want).max()), j
+        if small:
+            want_xt = orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), w1[j], b1[j], dils[j]).astype(np.float32)
+            want = orc.conv1d_np(orc.lrelu_np(want_xt, 0.1), w2[j], b2[j], 1) + xs[j]
+            assert np.abs(got[j] - want).max() <= 2 * TOL_LAYER * max(1.0, np.abs(want).max()), j
         assert np.array_equal(got[j], sep[j]), j
     # aliased buffers are refused (a block's window overlaps the rows its neighbours write)
-    status = lib.iris_hifigan_op_mrf_pair(
-        vp3(*[t.data_ptr() for t in xd]), fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]),
-        fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]), vp3(*[t.data_ptr() for t in xd]),
-        B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None)
-    assert status != 0
+    assert pair(xd, None, mode) != 0
+    if mode >= 1:
+        # the same launch as the LAST pair of a stage: only ((y_0 + y_1) + y_2) / 3 is stored (hifigan_pretrained.py:131-137),
+        # bit for bit the reference-order sum of the separate branch outputs
+        mean = torch.full((B, L, C), float("nan"), device="cuda")
+        _check("op_mrf_pair (summing)", pair(None, mean, mode))
+        got_mean = mean.cpu().numpy().transpose(0, 2, 1)
+        assert np.array_equal(got_mean, ((sep[0] + sep[1]) + sep[2]) / np.float32(3))
+        assert pair(None, xd[1], mode) != 0             # the mean may not overwrite an input either
+    else:
+        assert pair(None, torch.empty((B, L, C), device="cuda"), 0) == 4      # IRIS_HIFIGAN_UNSUPPORTED: mode 0 cannot sum
 
 
 def test_mrf_step_rejects_what_the_kernel_cannot_take(lib):
@@ -645,3 +663,27 @@ def test_integration_md_ctypes_stub_runs(dev):
     assert got.shape == want.shape == (2, 1, 40 * 256)
     # (the stub folds weight-norm with torch, the module with numpy: last-bit differences in the weights)
     assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_large_batch_runs_as_passes_sharing_one_workspace(dev):
+    """A batch of more than 65,536 mel frames runs as consecutive passes over sub-batches that share ONE workspace
+    (iris_hifigan_workspace_bytes is bounded: 15 GB instead of 229 KB x every frame).  Batch items are independent, so
+    every item must equal -- bit for bit -- the same item vocoded alone; checked on items of the first pass, across the
+    pass boundary and in the last (partial) pass."""
+    from iris import _native
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=77, gain=1.1, post_gain=8.0), dev)
+    B, T = 70, 1000                                    # 70,000 frames: a pass of 65 items and one of 5
+    plan = _native.describe_plan(cfg, B, T, _native.DTYPE_F32)
+    assert plan["passes"] == 2
+    assert eng.workspace_bytes(B, T) == eng.workspace_bytes(65, T) == plan["workspace_bytes"] < 16e9
+    mel = torch.from_numpy(seeded_mel(4242, B, T)).to(dev)
+    wav = eng.forward(mel)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wav).all()
+    for i in (0, 64, 65, 69):
+        alone = eng.forward(mel[i:i + 1].contiguous())
+        assert torch.equal(wav[i:i + 1], alone), i
+    eng.close()

@@ -186,10 +186,11 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iris_hifigan_abi_version() == _native.ABI_VERSION == 2
+    assert lib.iris_hifigan_abi_version() == _native.ABI_VERSION == 3
     assert ctypes.sizeof(_native.Config) == 4 * (3 + 8 + 8 + 1 + 8 + 8 + 64 + 2) + 4
     assert ctypes.sizeof(_native.LaunchRecord) == 40
     assert ctypes.sizeof(_native.WorkspaceMap) == 8 * (2 + 8 + 8 + 1) + 8
+    assert ctypes.sizeof(_native.PlanLaunch) == 80 + 4 * 4 + 8 and ctypes.sizeof(_native.Plan) == 24 + 96 * 104
 
 
 def test_cabi_argument_validation_without_gpu():
@@ -314,3 +315,66 @@ def test_model_repacks_after_in_place_parameter_edits(monkeypatch):
     assert m.engine() is e2
     m.invalidate()                                                    # ... so such edits are announced explicitly
     assert m.engine() is not e2 and built[-1] == 0.5 and len(built) == 3
+
+
+def test_model_built_under_inference_mode(monkeypatch):
+    """Tensors created under torch.inference_mode() have no version counter (reading ``_version`` raises): such a
+    model still builds its engine and keeps it until invalidate()."""
+    from iris import hifigan_pretrained as hp
+
+    class FakeEngine:
+        def __init__(self, cfg, sd, device):
+            self.device = device
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(hp, "GeneratorEngine", FakeEngine)
+    monkeypatch.setattr(hp, "require_gpu", lambda: torch.device("cpu"))
+    with torch.inference_mode():
+        m = hp.HiFiGANModel(upsample_initial_channel=32)
+        e1 = m.engine()
+        assert m.engine() is e1                                       # second call: the version check must not raise
+    assert m.engine() is e1
+    m.invalidate()
+    assert m.engine() is not e1
+
+
+def test_describe_plan_on_the_host():
+    """iris_hifigan_describe_plan: the forward's launch plan without a device -- the same code path as a forward
+    (argument checks, workspace layout, mrf_plan / pair plans), every launch recorded instead of issued."""
+    cfg = GeneratorConfig()
+    # configs[1]: 26 launches at 1000 frames (two fused conv pairs per narrow stage + the summing pair), 24 at 100 frames
+    p = _native.describe_plan(cfg, 1, 1000, _native.DTYPE_F32)
+    kernels = [l["kernel"] for l in p["launches"]]
+    assert p["n_launches"] == len(kernels) and kernels[0].startswith("conv_mfma_f32_kernel") and "conv_post" in kernels[-1]
+    assert sum(k.startswith("mrf_") for k in kernels) == p["n_launches"] - 6
+    assert all(1 <= l["grid"][0] and l["block"] == 256 and l["lds_bytes"] <= 160 * 1024 for l in p["launches"])
+    short = _native.describe_plan(cfg, 1, 100, _native.DTYPE_F32)
+    assert any(k == "mrf_small_f32_kernel" for k in (l["kernel"] for l in short["launches"]))   # stage 0 on short inputs
+    assert short["n_launches"] <= p["n_launches"]
+    # workspace figure == what the engine would be asked to provide (bytes per mel frame are constant)
+    assert p["workspace_bytes"] == 10 * short["workspace_bytes"] or abs(p["workspace_bytes"] / short["workspace_bytes"] - 10) < 1e-3
+    # bf16 configs[2]: fused pairs (persistent at C <= 64), no launch for xt
+    b16 = _native.describe_plan(cfg, 32, 500, _native.DTYPE_BF16)
+    assert sum("pair" in l["kernel"] for l in b16["launches"]) == 9 and b16["workspace_bytes"] < p["workspace_bytes"] * 16 * 0.51
+    # the plans are sized for the chip they are told about: a smaller one changes the persistent kernels' grids (and may
+    # change whether a stage's last pair forms the mean itself: whole-tile jobs must fill whole rounds of the chip)
+    small_chip = _native.describe_plan(cfg, 1, 1000, _native.DTYPE_F32, cu_count=64)
+    assert abs(small_chip["n_launches"] - p["n_launches"]) <= 2 and small_chip["cu_count"] == 64
+    assert [l["grid"] for l in small_chip["launches"]] != [l["grid"] for l in p["launches"]]
+    assert max(l["grid"][0] for l in small_chip["launches"] if "pf_kernel" in l["kernel"]) <= 64 * 4
+    # refusals are statuses, not crashes
+    with pytest.raises(_native.NativeCallError):
+        _native.describe_plan(cfg, 65536, 10)
+    with pytest.raises(_native.NativeCallError):
+        _native.describe_plan(cfg, 1, (1 << 30) // 256 + 1)
+    with pytest.raises(_native.NativeCallError, match="2\\^31"):
+        _native.describe_plan(cfg, 1, 1 << 18, _native.DTYPE_BF16)
+    assert _native.describe_plan(cfg, 0, 100)["n_launches"] == 0
+    # a large batch runs as passes over sub-batches that share one workspace: BASELINE.json configs[3] on one GPU
+    # (256 x 1000 frames) takes 4 passes of <= 65 items in 14.9 GB instead of one pass in 58 GB
+    big = _native.describe_plan(cfg, 256, 1000, _native.DTYPE_F32)
+    assert big["passes"] == 4 and big["workspace_bytes"] == 65 * p["workspace_bytes"] < 45e9
+    assert big["n_launches"] in (4 * p["n_launches"], 4 * p["n_launches"] - 4, 4 * p["n_launches"] - 8)
+    assert _native.describe_plan(cfg, 3, 70000)["passes"] == 3          # items longer than a pass: one item per pass
