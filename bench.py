@@ -552,7 +552,7 @@ def rank_main(args):
             del mel4, post
         except Exception as exc:
             out["configs4"] = {"error": str(exc)}
-        # ---- the one-GPU leg of configs[3]: batch 256 x 1000 frames fp32 (58 GB of workspace) -----------------------------
+        # ---- the one-GPU leg of configs[3]: batch 256 x 1000 frames fp32 (4 passes over sub-batches, 15 GB of workspace) ----
         try:
             m3 = torch.from_numpy(seeded_mel(1004, GLOBAL_BATCH, 1000)).to(dev)
             ms3, _, _ = timed_forward(eng, m3, "f32", 3, 1, dev, False, cfg)
@@ -563,7 +563,7 @@ def rank_main(args):
             del m3
         except Exception as exc:
             out["configs3_n1"] = {"error": str(exc)}
-        eng.release_workspace()                                           # the 58 GB, before the CPU leg
+        eng.release_workspace()                                           # the 15 GB, before the CPU leg
         torch.cuda.empty_cache()
 
     if world == 1 and not stub and not args.no_cpu_baseline:

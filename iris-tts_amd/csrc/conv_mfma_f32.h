@@ -209,56 +209,10 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
     const f32x4* wlane = wp + (size_t)ct * 64 + lane;
     const size_t wstep = (a.ablate & 2) ? 0 : (size_t)a.n_ct * 64;  // f32x4 elements per (tap, group)
 
-    // Chunk prefetch (layers with several C_in chunks and a short window: the ConvTranspose1d phases, PostNet): the quads of
-    // chunk c+1 are requested during the MFMAs of chunk c -- one per group, behind that group's weight request: vmcnt retires
-    // in order, so spread out each of them only delays the weight wait two groups later -- and written to LDS after them.
-    // Without it a block alternated between waiting for a chunk (an L2 round trip) and 16-32 groups of MFMAs: the
-    // upsamplers ran at half the fp32 MFMA roof.
-    constexpr int QPR = CIC / 4;
-    constexpr int PQ = 5;                                   // prefetched quads per thread: windows up to 256 * PQ / QPR rows
-    const int tid = threadIdx.x;
-    const bool pf = KS > 0 && !a.x_channels_first && (a.C_in & 3) == 0 && a.in_act != IN_ACT_MRF_LRELU && a.C_in > CIC &&
-                    R * QPR <= 256 * PQ && !(a.ablate & (1 | 64));      // (diagnostic builds: ablate bit 64 = no chunk prefetch)
-    f32x4 pre[PQ];
-    const float* pre_ptr[PQ];                               // quad i of chunk 0 (or the tensor's base when the quad is padding)
-    bool pre_ok[PQ];
-#pragma unroll
-    for (int i = 0; i < PQ; ++i) {
-        const int idx = i * 256 + tid;
-        const int r = idx / QPR, q = idx - r * QPR;
-        const int row = in_row0 + r;
-        pre_ok[i] = pf && idx < R * QPR && row >= 0 && row < a.L_in;
-        pre_ptr[i] = p.x + (pre_ok[i] ? ((size_t)b * a.L_in + row) * a.C_in + 4 * q : 0);
-    }
-    auto pf_issue_one = [&](int i, int c0n) {               // (always a valid address: the padding quads re-read the base)
-        const bool ok = pre_ok[i] && c0n + 4 * ((i * 256 + tid) % QPR) < a.C_in;
-        pre[i] = *reinterpret_cast<const f32x4*>(pre_ptr[i] + (ok ? c0n : 0));
-    };
-    auto pf_write = [&](int c0n) {
-#pragma unroll
-        for (int i = 0; i < PQ; ++i) {
-            const int idx = i * 256 + tid;
-            const int r = idx / QPR, q = idx - r * QPR;
-            if (idx < R * QPR) {
-                const bool ok = pre_ok[i] && c0n + 4 * q < a.C_in;
-                f32x4 v = ok ? pre[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-                if (a.in_act == IN_ACT_LRELU) v = lrelu4(v, a.slope);
-                *reinterpret_cast<f32x4*>(lds + r * S + 4 * q) = v;
-            }
-        }
-    };
-
     for (int c0 = 0; c0 < a.C_in; c0 += CIC) {
         if (c0 > 0) __syncthreads();
-        if (pf && c0 > 0) pf_write(c0);
-        else if (!(a.ablate & 1)) stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
+        if (!(a.ablate & 1)) stage_input<CIC>(a, p, lds, b, in_row0, R, c0);
         __syncthreads();
-        const bool pf_next = pf && c0 + CIC < a.C_in;
-        const int c0n = pf_next ? c0 + CIC : 0;             // (no next chunk: the requests below re-read the base, unused)
-        if (!wave_active && pf_next) {
-#pragma unroll
-            for (int i = 0; i < PQ; ++i) pf_issue_one(i, c0n);
-        }
         if (wave_active) {
             const int g0 = c0 >> 3;
             // One "group" = 8 input channels of one tap = 4*MT MFMAs.  Fragments of group n+1
@@ -293,23 +247,17 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
                 for (int n = 0; n < NG; n += 2) {
                     if (n + 1 < NG) load_a(av1, n + 1);
                     if (n + 2 < NG) bw2 = *b_ptr(n + 2);
-                    if (n < PQ) { if (pf) pf_issue_one(n, c0n); }
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_group(av0, bw0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (n + 1 < NG) {
                         if (n + 2 < NG) load_a(av0, n + 2);
                         if (n + 3 < NG) bw0 = *b_ptr(n + 3);
-                        if (n + 1 < PQ) { if (pf) pf_issue_one(n + 1, c0n); }
                         __builtin_amdgcn_sched_barrier(0);
                         mfma_group(av1, bw1);
                         __builtin_amdgcn_sched_barrier(0);
                         bw1 = bw0; bw0 = bw2;                  // rotate: bw0 <- group n+2, bw1 <- group n+3
                     }
-                }
-                if (pf) {
-#pragma unroll
-                    for (int i = NG; i < PQ; ++i) pf_issue_one(i, c0n);   // (fewer groups than quads: the rest behind the loop)
                 }
             } else {
                 for (int n = 0; n < n_groups; ++n) {
@@ -551,7 +499,11 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const long long blocks2 = (long long)((a.n_idx + t.T_BLK - 1) / t.T_BLK) * a.n_co_blk * nz * a.B;
     // (the last ConvTranspose1d -- K = 2 taps x 64 channels, 32 output channels: three quarters of a block's life is window load
     //  and store -- runs better as four 35 KB blocks per CU than as two 70 KB ones: 50 -> 43 us at batch 1 x 1000 frames)
+#ifdef IRIS_CONV_LAST_UPS_MT2
+    const bool tall_small_k = false;         // (A/B build)
+#else
     const bool tall_small_k = a.z_is_phase && t.WT == 4 && a.C_in <= 64;
+#endif
     const int MT = mt_env ? mt_env : ((blocks2 < 2LL * n_cu || tall_small_k) ? 1 : 2);
     const int T_BLK = t.WT * MT * 32;
     // conv_pre of the V1 generator (80 mel bins, channels-first -> 512): one 80-channel chunk instead of 64 + 16.  The launch

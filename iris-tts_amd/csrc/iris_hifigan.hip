@@ -554,7 +554,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                 const long long tiles_pf = (long long)((L_out + (pt.M - 10) - 1) / (pt.M - 10)) * B;
                 pf = IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_PF_MODE", 0) == 2 && pair_pf_f32_applicable(pa0, nk, false);
                 const int sum_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_SUM", 1);          // 0 never, 1 by size, 2 always
-                if (use_sum && sum_env && pair_pf_f32_applicable(pa0, nk, true)) {
+                if (use_sum && sum_env != 0 && pair_pf_f32_applicable(pa0, nk, true)) {
                     const PairPfPlanF32 sp = pair_pf_f32_plan(tiles_pf, device_cu_count(), pt.MINB, true);
                     fused_sum = sum_env == 2 || (sp.efficiency >= 0.85 && tiles_pf >= 4LL * device_cu_count() * sp.per_cu);
                 }

@@ -38,6 +38,9 @@ namespace iris {
 #ifndef IRIS_MRF_MINWAVES
 #define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef IRIS_MRF_DBUF
+#define IRIS_MRF_DBUF 0          // 1 = two LDS window buffers for the wide stages (see DBUF below): measured, no gain -- off
+#endif
 
 constexpr int kMrfSpanMax = 50;  // (ks-1)*dil of the widest supported conv: k=11, d=5
 
@@ -74,6 +77,15 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     constexpr int T_BLK = WT * MT * 32;
     constexpr int NQ = ((T_BLK + kMrfSpanMax) * QPR + 255) / 256;  // staged 16-byte quads per thread
     constexpr int RPI = 256 / QPR;                                   // rows advanced per staged quad
+    // Wide stages (WT == 1: C >= 128, 64-channel chunks, phases of >= 24 groups): TWO window buffers.  The quads of phase
+    // p+1 are written into the other buffer during the LAST NQ groups of phase p's MFMA loop -- behind MFMAs, where a
+    // ds_write_b128 costs nothing -- so a phase ends with ONE barrier instead of barrier + LDS write + barrier (round 2's
+    // stamps: LDS write 2.6-3 % + second barrier 0.5 % of a wave's life at C = 256 / 128).  62-70 KB per block, two blocks per CU.
+    // Measured in round 3 (profiles/r03_notes.md): bit-identical, and no faster -- the CU's other block covers that time
+    // already -- so it is compiled out by default (IRIS_MRF_DBUF).
+    constexpr bool DBUF = (WT == 1) && (IRIS_MRF_DBUF != 0);
+    constexpr int BUF_ROWS = DBUF ? NQ * RPI : T_BLK + kMrfSpanMax;  // (DBUF: every staged quad has a row, written unconditionally)
+    constexpr int BUF_FLOATS = BUF_ROWS * S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave / WC, wc = wave - wt * WC;
@@ -93,6 +105,11 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     constexpr int ablate = 0;
 #endif
     const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
+#ifdef IRIS_MRF_BLOCKLOG
+    // diagnostic build only (make variant NAME=blocklog EXTRA=-DIRIS_MRF_BLOCKLOG): every block leaves its start / end time on the
+    // constant 100 MHz clock and the CU it ran on, for a per-CU timeline of the launch
+    const unsigned long long blk_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef IRIS_MRF_DIAG
     // A/B (profiles/r03_notes.md): the two blocks of a CU run the same equal-cost sequence and would stay in lock-step; delay
     // the second residency generation by a.stagger x 1,024 cycles
@@ -142,6 +159,13 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         // they would be real rows of the tensor, i.e. HBM reads that nobody uses
         st[i] = buf_load4(xr, r_lane + i * RPI < R ? vbase + (unsigned)i * row_stride : kOobOffset, 0);
     };
+    int cur = 0;                             // DBUF: the buffer the current phase reads
+    auto stage_write_one = [&](int i, float* dst) {   // DBUF: quad i of the next phase's window -> the other buffer
+        f32x4 v = st[i];                     // (rows past the window were requested out of range: zeros; their rows exist)
+        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+        *reinterpret_cast<f32x4*>(dst + i * RPI * S) = v;
+    };
     auto stage_write_all = [&](int R) {      // LeakyReLU on the way in (hifigan_pretrained.py:66,68)
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
@@ -150,7 +174,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 f32x4 v = st[i];
                 v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
                 v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-                *reinterpret_cast<f32x4*>(lds_wr + i * RPI * S) = v;
+                *reinterpret_cast<f32x4*>(lds_wr + cur * BUF_FLOATS + i * RPI * S) = v;
             }
     };
 
@@ -233,7 +257,9 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             const unsigned wsoffn = last ? 0u : (unsigned)((chunk + 1) * GPC) * wbytes_group;
             const unsigned wvoffn = cross ? tn.wvoff : t.wvoff;
 
-            auto a_ptr = [&](int n) { return aptr + (n / GPC) * dilS + 8 * (n % GPC); };
+            const float* const aptr_c = aptr + cur * BUF_FLOATS;
+            float* const lds_wr_n = lds_wr + (cur ^ 1) * BUF_FLOATS;
+            auto a_ptr = [&](int n) { return aptr_c + (n / GPC) * dilS + 8 * (n % GPC); };
             auto b_load = [&](int n, unsigned voff_next) {   // group n of this phase, or group n-NG of the next one
                 if (n < NG)
                     return buf_load4(wr, t.wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
@@ -262,6 +288,10 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                         if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
                 }
                 if (!(ablate & 32)) bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
+                if constexpr (DBUF) {
+                    static_assert(!DBUF || NG >= 2 * NQ, "a phase must be long enough to request and write the next window");
+                    if (n >= NG - NQ) stage_write_one(n - (NG - NQ), lds_wr_n);
+                }
                 if (n + 1 < NG) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -367,7 +397,16 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #ifdef IRIS_MRF_STAMPS
             if (last) seg[7] += ts2 - ts1;
 #endif
-            if (has_next) {
+            if (DBUF && has_next) {
+                if (stored) {
+#pragma unroll
+                    for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));   // (keep-alive, see below)
+                }
+                __syncthreads();          // every wave is done reading this window AND has written its share of the next one
+                cur ^= 1;
+                IRIS_STAMP(ts5);
+                IRIS_SEG(2, ts2, ts5);
+            } else if (has_next) {
                 __syncthreads();          // every wave is done reading this chunk's window
                 IRIS_STAMP(ts3);
                 stage_write_all(Rn);
@@ -414,7 +453,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         // dynamic mode: the next tile index comes from a global counter (first tile = blockIdx.x).  Thread 0 fetches
         // it at the start of a tile and leaves it in an LDS word behind the window; everybody reads it after the
         // barriers that end the first branch -- long before the last branch needs it for its prefetch.
-        unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (T_BLK + kMrfSpanMax) * S);
+        unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (DBUF ? 2 : 1) * BUF_FLOATS);
         for (;;) {
             if (a.dyn_counter && tid == 0) *next_slot = gridDim.x + atomicAdd(a.dyn_counter, 1u);
             run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
@@ -455,6 +494,15 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         else if (zb == 1) walk(std::integral_constant<int, KB>{}, I1{});
         else              walk(std::integral_constant<int, KA>{}, I0{});
     }
+#ifdef IRIS_MRF_BLOCKLOG
+    if (tid == 0 && a.dbg) {
+        unsigned long long* rec = a.dbg + 4 * (size_t)blockIdx.x;
+        rec[0] = blk_t0;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID: cu / sh / se
+        rec[3] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));     // HW_REG_XCC_ID
+    }
+#endif
 #ifdef IRIS_MRF_STAMPS
     seg[5] = stamp() - t_entry;
     if (lane == 0 && a.dbg) {
@@ -618,7 +666,11 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
     if (pl.small) return launch_mrf_small(a, nz, stream);
     const int T_BLK = t.WT * pl.MT * 32;
-    const size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;   // + next-tile word
+    size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;         // + next-tile word
+    if (t.WT == 1 && IRIS_MRF_DBUF) {    // two window buffers of NQ * RPI rows (see the kernel)
+        const int qpr = t.CIC / 4, nq = ((T_BLK + kMrfSpanMax) * qpr + 255) / 256, rpi = 256 / qpr;
+        lds_bytes = (size_t)2 * nq * rpi * (t.CIC + 4) * sizeof(float) + 16;
+    }
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
     const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
     if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
@@ -640,6 +692,12 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, true>);   \
         else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, false>);  \
     } while (0)
+#ifdef IRIS_MRF_BLOCKLOG
+    static unsigned long long* blk_dev = nullptr;
+    if (!blk_dev) { if (hipMalloc(&blk_dev, 4096 * 4 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
+    (void)hipMemsetAsync(blk_dev, 0, 4096 * 4 * sizeof(unsigned long long), stream);
+    a.dbg = g <= 4096 ? blk_dev : nullptr;
+#endif
 #ifdef IRIS_MRF_STAMPS
     static unsigned long long* dbg_dev = nullptr;
     if (!dbg_dev) { if (hipMalloc(&dbg_dev, 16 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory; }
@@ -662,6 +720,36 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
                 a.C_in, a.L_in, g, nw, tot / nw, mfma_cyc, mfma_cyc / (tot / nw), h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot,
                 1.0 - (h[0] + h[1] + h[2] + h[3] + h[4]) / tot);
         fprintf(stderr, "[stamps]   of the epilogue: adds (incl. wait for residual) %.3f, whole last-chunk epilogue %.3f\n", h[8] / tot, h[9] / tot);
+    }
+#endif
+#ifdef IRIS_MRF_BLOCKLOG
+    if (a.dbg && IRIS_DIAG_ENV("IRIS_HIFIGAN_BLOCKLOG", 0)) {   // synchronous read-back: one line per launch + per-CU detail of the slowest CUs
+        static unsigned long long hrec[4096 * 4];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(hrec, blk_dev, (size_t)g * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long tmin = ~0ull, tmax = 0; double busy = 0; int n = 0;
+        static int per_cu[8 * 64 * 16]; memset(per_cu, 0, sizeof(per_cu));
+        static unsigned long long cu_end[8 * 64 * 16]; memset(cu_end, 0, sizeof(cu_end));
+        for (long long i = 0; i < g; ++i) {
+            const unsigned long long t0 = hrec[4 * i], t1 = hrec[4 * i + 1];
+            if (!t1) continue;
+            const unsigned hw = (unsigned)hrec[4 * i + 2], xcc = (unsigned)hrec[4 * i + 3] & 15u;
+            const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+            const unsigned key = ((xcc * 8 + se) * 2 + sh) * 16 + cu;
+            if (key < sizeof(per_cu) / sizeof(per_cu[0])) { per_cu[key]++; if (t1 > cu_end[key]) cu_end[key] = t1; }
+            if (t0 < tmin) tmin = t0;
+            if (t1 > tmax) tmax = t1;
+            busy += (double)(t1 - t0); ++n;
+        }
+        int cus = 0, hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double end_sum = 0, end_min = 1e30;
+        for (size_t k = 0; k < sizeof(per_cu) / sizeof(per_cu[0]); ++k)
+            if (per_cu[k]) { ++cus; hist[per_cu[k] < 7 ? per_cu[k] : 7]++; const double e = (double)(cu_end[k] - tmin); end_sum += e; if (e < end_min) end_min = e; }
+        const double span = (double)(tmax - tmin);
+        fprintf(stderr, "[blocklog] C=%d L=%d grid=%lld blocks=%d CUs=%d blocks/CU hist 1:%d 2:%d 3:%d 4:%d 5+:%d | span %.1f us, mean block %.1f us, "
+                        "block-residency %.3f of 2 per CU over the span | CU finish: earliest %.3f mean %.3f of the span\n",
+                a.C_in, a.L_in, g, n, cus, hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6] + hist[7], span / 100.0, busy / n / 100.0,
+                busy / (span * cus), end_min / span, end_sum / cus / span);
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB

@@ -100,7 +100,8 @@ class GeneratorEngine:
         return self._workspace
 
     def release_workspace(self) -> None:
-        """Frees the activation workspace (it grows to the largest shape seen: 229 KB per mel frame in fp32) and the
+        """Frees the activation workspace (it grows to the largest shape seen: 229 KB per mel frame in fp32, bounded at 65,536
+        frames = 15 GB because larger batches run as passes over sub-batches) and the
         captured graphs that point into it; the next forward allocates what it needs."""
         self._graphs = {}
         self._workspace = None

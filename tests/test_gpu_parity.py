@@ -687,3 +687,31 @@ def test_large_batch_runs_as_passes_sharing_one_workspace(dev):
         alone = eng.forward(mel[i:i + 1].contiguous())
         assert torch.equal(wav[i:i + 1], alone), i
     eng.close()
+
+
+def test_prepare_and_profiling_survive_graph_capture(dev):
+    """ABI v3: the packings beyond fp32 are built on first use (iris_hifigan_prepare, or the first forward of the dtype), and
+    capturing a forward into a hipGraph while profiling is on PAUSES the records instead of resetting them."""
+    from iris._engine import GeneratorEngine
+    from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
+    cfg = GeneratorConfig()
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=5, gain=1.1, post_gain=6.0), dev)
+    mel = torch.from_numpy(seeded_mel(8, 1, 40)).to(dev)
+    eng.prepare("bf16")                                   # explicit: nothing left to build inside the capture below
+    eng.prepare("bf16")                                   # idempotent
+    eng.set_profiling(1)
+    want = eng.forward(mel).clone()
+    torch.cuda.synchronize()
+    n_one = len(eng.read_profile())
+    assert n_one >= 20
+    got = eng.forward_graph(mel)                          # first use of this shape: warm-up + capture, profiling paused
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert len(eng.read_profile()) == n_one               # the records of the eager forward are still there, none were added
+    eng.forward(mel)
+    torch.cuda.synchronize()
+    assert len(eng.read_profile()) == 2 * n_one           # ... and profiling is on again
+    b16 = eng.forward_graph(mel, dtype="bf16")            # captured without a lazy build inside the capture
+    torch.cuda.synchronize()
+    assert torch.isfinite(b16).all() and (b16 - want).abs().max() <= 6e-2
+    eng.close()

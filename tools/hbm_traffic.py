@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """HBM traffic per dispatch of the last forward from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
 usage: tools/hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [plan]
-plan = one letter per launch of a forward: P conv_pre, U upsample, M MRF launch, O conv_post.  Default: the fp32 path of a
-large problem (P + 2 x (U + 6 M) + 2 x (U + 4 M) + O = 26 launches: the C = 64 / 32 stages run two fused conv pairs and the
-two steps of the last pair); the bf16 path with fused conv pairs at C <= 128 is PUMMMMMMUMMMUMMMUMMMO (21).
+plan = one letter per launch of a forward: P conv_pre, U upsample, M MRF launch, O conv_post.  Default: derived from the
+kernel names of the last forward in the trace (fp32, batch 1 x 1000: P + 2 x (U + 6 M) + (U + 4 M) + (U + 3 M) + O = 25 launches;
+bf16 with fused conv pairs at C <= 128: PUMMMMMMUMMMUMMMUMMMO, 21).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2*FETCH_SIZE*1024;
 WRITE_SIZE*1024 is exact."""
 import collections, csv, json, sys
@@ -15,9 +15,19 @@ def load(path, counter):
             d[int(r["Dispatch_Id"])] = (r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"]))
     return list(d.values())
 
-plan = sys.argv[4] if len(sys.argv) > 4 else "P" + ("U" + "M" * 6) * 2 + ("U" + "M" * 4) * 2 + "O"
+fetch_all, write_all = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+if len(sys.argv) > 4:
+    plan = sys.argv[4]
+else:
+    # the last forward = the dispatches behind the second-to-last conv_post up to the last one; one letter per launch by kernel name
+    posts = [i for i, (kn, _, _) in enumerate(fetch_all) if "conv_post" in kn]
+    assert len(posts) >= 2, "need at least two forwards in the trace"
+    names = [kn for kn, _, _ in fetch_all[posts[-2] + 1:posts[-1] + 1]]
+    while names and "iris" not in names[0]:          # (the runtime's own memset kernel in front of a forward is not a launch of ours)
+        names.pop(0)
+    plan = "".join("O" if "conv_post" in kn else ("M" if "mrf_" in kn else ("P" if i == 0 else "U")) for i, kn in enumerate(names))
 n = len(plan)
-fetch, write = load(sys.argv[1], "FETCH_SIZE")[-n:], load(sys.argv[2], "WRITE_SIZE")[-n:]
+fetch, write = fetch_all[-n:], write_all[-n:]
 assert len(fetch) == len(write) == n, (len(fetch), len(write))
 rows, mrf = [], []
 mrf_pos = {i for i, c in enumerate(plan) if c == "M"}
@@ -28,7 +38,7 @@ for pos, ((kn, grid, f), (kn2, _, w)) in enumerate(zip(fetch, write)):
     rows.append({"kernel": name, "grid": grid, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "traffic_bytes_corrected": t})
     if pos in mrf_pos:
         mrf.append(t)
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes); last forward (%d dispatches)" % n,
+out = {"plan": plan, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes); last forward (%d dispatches)" % n,
        "correction": "gfx950: read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 exact (MI355X_MICROARCH.md, HBM)",
        "mrf_launches": len(mrf), "mrf_traffic_bytes_per_launch": (sum(mrf) / len(mrf)) if mrf else None, "per_dispatch": rows}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
