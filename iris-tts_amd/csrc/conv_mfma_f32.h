@@ -30,6 +30,9 @@
 // one stage, kernel sizes 3/7/11: three ResBlocks advance in one launch) or the ConvTranspose phase.
 #pragma once
 #include "device_info.h"
+#ifndef IRIS_CONV_WEIGHT_RING
+#define IRIS_CONV_WEIGHT_RING 4   // groups the generic conv kernel's weight fragments run ahead of their use (A/B builds: 2)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -237,27 +240,22 @@ __device__ __forceinline__ void conv_body(const ConvLaunch& a, const ConvProblem
             };
             if constexpr (KS > 0) {
                 constexpr int NG = KS * GPC;
-                f32x4 av0[MT], av1[MT], bw0, bw1, bw2;
-                load_a(av0, 0);
-                bw0 = *b_ptr(0);
-                bw1 = *b_ptr(NG > 1 ? 1 : 0);
+                // Weight fragments run DBW groups ahead in a register ring (round 3: four instead of two: -1.5 us on the first
+                // ConvTranspose1d and -0.6 us on conv_pre at 100 frames, neutral at 1000 -- profiles/r03o_conv_weight_ring_ab.txt).
                 // sched_barrier(0): hipcc otherwise sinks every load back next to its first use
-                // (global_load followed by vmcnt(0)), exposing the L2 latency once per group.
+                // (global_load followed by vmcnt(0)), exposing the latency once per group.
+                constexpr int DBW = IRIS_CONV_WEIGHT_RING;
+                f32x4 av[2][MT], bwr[DBW + 1];
 #pragma unroll
-                for (int n = 0; n < NG; n += 2) {
-                    if (n + 1 < NG) load_a(av1, n + 1);
-                    if (n + 2 < NG) bw2 = *b_ptr(n + 2);
+                for (int d = 0; d < DBW; ++d) bwr[d] = *b_ptr(d < NG ? d : NG - 1);
+                load_a(av[0], 0);
+#pragma unroll
+                for (int n = 0; n < NG; ++n) {
+                    if (n + 1 < NG) load_a(av[(n + 1) & 1], n + 1);
+                    if (n + DBW < NG) bwr[(n + DBW) % (DBW + 1)] = *b_ptr(n + DBW);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_group(av0, bw0);
+                    mfma_group(av[n & 1], bwr[n % (DBW + 1)]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (n + 1 < NG) {
-                        if (n + 2 < NG) load_a(av0, n + 2);
-                        if (n + 3 < NG) bw0 = *b_ptr(n + 3);
-                        __builtin_amdgcn_sched_barrier(0);
-                        mfma_group(av1, bw1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        bw1 = bw0; bw0 = bw2;                  // rotate: bw0 <- group n+2, bw1 <- group n+3
-                    }
                 }
             } else {
                 for (int n = 0; n < n_groups; ++n) {
