@@ -227,8 +227,9 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
  * on fp32 channels-last tensors [B, L, C].  mean_dev != NULL makes it the last step of a stage: only
  * ((y_0 + y_1) + y_2) / 3 is stored, into mean_dev (y_dev is then unused).
  * plan: 0 = the library's own choice, 1 = persistent blocks with full-height tiles, 2 = with half-height tiles,
- * 3 = one branch per block, 4 = the small-problem kernel (16 x 16 jobs on v_mfma_f32_16x16x4_f32); all of them produce
- * identical bits.  mean_dev is available in plans 0-2.  Returns IRIS_HIFIGAN_UNSUPPORTED when the shape cannot take
+ * 3 = one branch per block, 4 = the small-problem kernel (16 x 16 jobs on v_mfma_f32_16x16x4_f32), 5 / 6 = (tile, branch)
+ * jobs drawn from a counter at half / full tile height (C >= 128); all of them produce identical bits.  mean_dev is
+ * available in plans 0-2.  Returns IRIS_HIFIGAN_UNSUPPORTED when the shape cannot take
  * the requested kernel. */
 int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* w_host, const float* const* bias_host,
                                  const float* const* res_dev, float* const* y_dev, float* mean_dev,

@@ -886,7 +886,7 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
     IRIS_ABI_BEGIN
     if (!x_dev || !w_host || !bias_host || !k || !dil || (!y_dev && !mean_dev))
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
-    if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 4) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
+    if (B < 1 || L < 1 || C < 1 || plan < 0 || plan > 6) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_step shape or plan");
     const int nk = 3;
     for (int j = 0; j < nk; ++j) {
         if (!x_dev[j] || !w_host[j] || !bias_host[j] || (!mean_dev && !y_dev[j])) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
@@ -921,9 +921,10 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
         for (int j = 0; j < nk; ++j) if (!a.p[j].y) a.p[j].y = mean_dev;     // never written; keeps descriptors valid
     }
     if (!mrf_kernel_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "shape cannot take the MRF kernel");
-    const int force = plan == 0 ? -1 : (plan == 4 ? 4 : plan - 1);
-    if (mean_dev && (force == 2 || force == 4)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block modes cannot form the mean");
+    const int force = plan == 0 ? -1 : (plan >= 4 ? plan : plan - 1);
+    if (mean_dev && (force == 2 || force >= 4)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the one-branch-per-block modes cannot form the mean");
     if (force == 4 && !mrf_small_applicable(a, nk)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the small-problem kernel needs C %% 32 == 0");
+    if (force >= 5 && !mrf_plan(a, true, force).zdyn) return fail(IRIS_HIFIGAN_UNSUPPORTED, "the job mode needs two or more C_in chunks (C >= 128)");
     HIP_TRY(launch_mrf_conv(a, nk, stream, force));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;

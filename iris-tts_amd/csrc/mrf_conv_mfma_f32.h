@@ -21,6 +21,7 @@
 #pragma once
 #include <stdio.h>
 #include <type_traits>
+#include <string.h>
 #include "conv_mfma_f32.h"
 
 namespace iris {
@@ -31,6 +32,15 @@ namespace iris {
 #define IRIS_MRF_ABLATE(a) 0
 #endif
 
+#ifndef IRIS_MRF_FORCE_PLAN
+#define IRIS_MRF_FORCE_PLAN (-1)         // calibration builds (make relvariant EXTRA=-DIRIS_MRF_FORCE_PLAN=n): every launch in plan n
+#endif
+#ifndef IRIS_MRF_ZDYN_DEFAULT
+#define IRIS_MRF_ZDYN_DEFAULT 1          // (tile, branch) jobs from a counter where the estimate favours them (A/B builds: 0)
+#endif
+#ifndef IRIS_MRF_ZDYN_OVERHEAD
+#define IRIS_MRF_ZDYN_OVERHEAD 1.02
+#endif
 #ifndef IRIS_ZPAR_ONE_PER_CU_DEFAULT
 #define IRIS_ZPAR_ONE_PER_CU_DEFAULT 1   // (A/B builds: 0 = one-branch-per-block mode always spreads over every block slot)
 #endif
@@ -67,8 +77,14 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t rsrc,
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)voff, (int)soff, 0);
 }
 constexpr unsigned kOobOffset = 0x80000000u;  // >= any num_records used here
+template <class T>
+__device__ __forceinline__ T* uniform_ptr_mrf(T* p) {     // a block-uniform pointer, pinned to SGPRs
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
 
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, bool ZPAR>
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR>
 __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = CIC + 4;
@@ -201,13 +217,16 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     f32x4 bw[DB + 1];     // ring of weight fragments; groups 0..DB-1 of a phase are requested by the
                           // phase before it (or by the prologue)
 
-    // One branch (problem p, KS taps) of tile `t`: all C_in chunks, then its epilogue.
-    // (pn, tn) = the phase that follows this branch's last chunk -- the next branch of the same tile,
-    // or the first branch of the block's next tile -- or pn == nullptr at the very end.
-    auto run_branch = [&](auto ks_tag, auto pi_tag, auto pn_tag, const Tile& t, const bool next_valid, const Tile& tn) {
+    // What follows a branch's last chunk: the next branch of the same tile, a branch of the block's next tile or job -- or
+    // nothing (valid == false) at the very end.
+    struct NextJob { bool valid; size_t batch_off; int i0; unsigned wvoff; const float* x; const f32x4* wp; int ks, dil, pad_left; };
+
+    // One branch (problem p, KS taps) of tile `t`: all C_in chunks, then its epilogue.  get_next() is called once, at the
+    // start of the branch's LAST chunk (with jobs drawn from a counter the answer is only known by then), and says which
+    // window and weights the last chunk prefetches.
+    auto run_branch = [&](auto ks_tag, auto pi_tag, const Tile& t, auto get_next) {
         constexpr int KS = decltype(ks_tag)::value;
         constexpr int PI = decltype(pi_tag)::value;   // index of this branch's problem in a.p[]
-        constexpr int PN = decltype(pn_tag)::value;   // index of the problem whose window follows
         constexpr int NG = KS * GPC;
         const ConvProblem& p = a.p[PI];               // constant index: stays in the kernarg segment
         const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, (unsigned)(KS * a.Gp) * wbytes_group);
@@ -238,24 +257,29 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 
         for (int chunk = 0; chunk < n_chunks; ++chunk) {
             const bool last = chunk + 1 == n_chunks;
+            NextJob nj;
+            nj.valid = false; nj.batch_off = t.batch_off; nj.i0 = t.i0; nj.wvoff = t.wvoff;
+            nj.x = p.x; nj.wp = p.wp; nj.ks = KS; nj.dil = p.dil; nj.pad_left = p.pad_left;
+            if (last) nj = get_next();
+            const bool next_valid = nj.valid;
             const bool has_next = !last || next_valid;
             f32x4 outv[MT * 4];        // store data of this branch's epilogue (see keep-alive below)
             bool stored = false;
-            // the phase that follows: next chunk of this branch, or chunk 0 of (a.p[PN], tn)
+            // the phase that follows: next chunk of this branch, or chunk 0 of the next job
             const bool cross = last && next_valid;
-            const float* xq = cross ? a.p[PN].x + tn.batch_off : p.x + t.batch_off;
-            const f32x4* wq = cross ? a.p[PN].wp : p.wp;
-            const int ksq = cross ? a.p[PN].ks : KS;
-            const int dilq = cross ? a.p[PN].dil : p.dil;
-            const int padq = cross ? a.p[PN].pad_left : p.pad_left;
-            const int i0q = cross ? tn.i0 : t.i0;
+            const float* xq = cross ? nj.x + nj.batch_off : p.x + t.batch_off;
+            const f32x4* wq = cross ? nj.wp : p.wp;
+            const int ksq = cross ? nj.ks : KS;
+            const int dilq = cross ? nj.dil : p.dil;
+            const int padq = cross ? nj.pad_left : p.pad_left;
+            const int i0q = cross ? nj.i0 : t.i0;
             const __amdgpu_buffer_rsrc_t xrn = make_rsrc(xq, tensor_bytes);
             const __amdgpu_buffer_rsrc_t wrn = make_rsrc(wq, (unsigned)(ksq * a.Gp) * wbytes_group);
             const int Rn = T_BLK + (ksq - 1) * dilq;
             const unsigned vbn = stage_vbase(i0q - padq, last ? 0 : (chunk + 1) * CIC);
             const unsigned wsoff0 = (unsigned)(chunk * GPC) * wbytes_group;
             const unsigned wsoffn = last ? 0u : (unsigned)((chunk + 1) * GPC) * wbytes_group;
-            const unsigned wvoffn = cross ? tn.wvoff : t.wvoff;
+            const unsigned wvoffn = cross ? nj.wvoff : t.wvoff;
 
             const float* const aptr_c = aptr + cur * BUF_FLOATS;
             float* const lds_wr_n = lds_wr + (cur ^ 1) * BUF_FLOATS;
@@ -429,13 +453,11 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     using I2 = std::integral_constant<int, 2>;
     // prologue: the first window and the first weight fragments of problem PI (the only latencies a
     // block exposes)
-    auto prologue = [&](auto pi_tag, const Tile& t) {
-        constexpr int PI = decltype(pi_tag)::value;
-        const ConvProblem& p0 = a.p[PI];
-        const int R0 = T_BLK + (p0.ks - 1) * p0.dil;
-        const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(p0.x + t.batch_off, tensor_bytes);
-        const __amdgpu_buffer_rsrc_t wr0 = make_rsrc(p0.wp, (unsigned)(p0.ks * a.Gp) * wbytes_group);
-        const unsigned vb0 = stage_vbase(t.i0 - p0.pad_left, 0);
+    auto prologue = [&](const float* x0, const f32x4* wp0, int ks0, int dil0, int pad0, const Tile& t) {
+        const int R0 = T_BLK + (ks0 - 1) * dil0;
+        const __amdgpu_buffer_rsrc_t xr0 = make_rsrc(x0 + t.batch_off, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t wr0 = make_rsrc(wp0, (unsigned)(ks0 * a.Gp) * wbytes_group);
+        const unsigned vb0 = stage_vbase(t.i0 - pad0, 0);
 #pragma unroll
         for (int i = 0; i < NQ; ++i) stage_load_one(i, xr0, vb0, R0);
 #pragma unroll
@@ -443,30 +465,39 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         stage_write_all(R0);
         __syncthreads();
     };
-    if constexpr (!ZPAR) {
+    // the next job when it is problem a.p[PN] (constant index: the kernel arguments stay in SGPRs) of tile tn
+    auto next_of = [&](auto pn_tag, bool valid, const Tile& tn) {
+        constexpr int PN = decltype(pn_tag)::value;
+        // (pinned to SGPRs here: a select between fields of the kernel-argument struct is otherwise turned into a load from a
+        //  selected ADDRESS, i.e. a table in private memory)
+        return NextJob{valid, tn.batch_off, tn.i0, tn.wvoff, uniform_ptr_mrf(a.p[PN].x), uniform_ptr_mrf(a.p[PN].wp),
+                       __builtin_amdgcn_readfirstlane(a.p[PN].ks), __builtin_amdgcn_readfirstlane(a.p[PN].dil),
+                       __builtin_amdgcn_readfirstlane(a.p[PN].pad_left)};
+    };
+    unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (DBUF ? 2 : 1) * BUF_FLOATS);   // LDS word: a drawn tile / job index
+    if constexpr (ZPAR == 0) {
         // equal-cost blocks: every block runs all three branches of its tiles, heaviest first:
         // p[2] (KC taps), p[1] (KB), p[0] (KA); persistent over tiles
         int tile = blockIdx.x;
         if (tile >= n_tiles) return;
         Tile t = make_tile(tile);
-        prologue(I2{}, t);
+        prologue(a.p[2].x, a.p[2].wp, a.p[2].ks, a.p[2].dil, a.p[2].pad_left, t);
         // dynamic mode: the next tile index comes from a global counter (first tile = blockIdx.x).  Thread 0 fetches
         // it at the start of a tile and leaves it in an LDS word behind the window; everybody reads it after the
         // barriers that end the first branch -- long before the last branch needs it for its prefetch.
-        unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (DBUF ? 2 : 1) * BUF_FLOATS);
         for (;;) {
             if (a.dyn_counter && tid == 0) *next_slot = gridDim.x + atomicAdd(a.dyn_counter, 1u);
-            run_branch(std::integral_constant<int, KC>{}, I2{}, I1{}, t, true, t);
+            run_branch(std::integral_constant<int, KC>{}, I2{}, t, [&] { return next_of(I1{}, true, t); });
             const int tile_next = a.dyn_counter ? (int)*next_slot : tile + (int)gridDim.x;
             const bool more = (unsigned)tile_next < (unsigned)n_tiles;
             const Tile tn = make_tile(more ? tile_next : tile);
-            run_branch(std::integral_constant<int, KB>{}, I1{}, I0{}, t, true, t);
-            run_branch(std::integral_constant<int, KA>{}, I0{}, I2{}, t, more, tn);
+            run_branch(std::integral_constant<int, KB>{}, I1{}, t, [&] { return next_of(I0{}, true, t); });
+            run_branch(std::integral_constant<int, KA>{}, I0{}, t, [&] { return next_of(I2{}, more, tn); });
             if (!more) break;
             tile = tile_next;
             t = tn;
         }
-    } else {
+    } else if constexpr (ZPAR == 1) {
         // One branch per block: a stage step is spread over 3x the jobs, which fills the chip when there are fewer
         // tiles than block slots and softens the round quantisation of the tile-serial mode in between.  Each
         // branch has its own range of blocks, sized by the host so that the three finish together (mrf_plan):
@@ -479,12 +510,13 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         if (tile >= n_tiles) return;
         Tile t = make_tile(tile);
         auto walk = [&](auto ks_tag, auto pi_tag) {
-            prologue(pi_tag, t);
+            constexpr int PI = decltype(pi_tag)::value;
+            prologue(a.p[PI].x, a.p[PI].wp, a.p[PI].ks, a.p[PI].dil, a.p[PI].pad_left, t);
             for (;;) {
                 const int tile_next = tile + step;
                 const bool more = tile_next < n_tiles;
                 const Tile tn = make_tile(more ? tile_next : tile);
-                run_branch(ks_tag, pi_tag, pi_tag, t, more, tn);
+                run_branch(ks_tag, pi_tag, t, [&] { return next_of(pi_tag, more, tn); });
                 if (!more) break;
                 tile = tile_next;
                 t = tn;
@@ -493,6 +525,53 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         if (zb == 2)      walk(std::integral_constant<int, KC>{}, I2{});
         else if (zb == 1) walk(std::integral_constant<int, KB>{}, I1{});
         else              walk(std::integral_constant<int, KA>{}, I0{});
+    } else {
+        // (tile, branch) JOBS in a fixed "snake" order (round 3).  Job j = branch 2 - j / n_tiles (all k = 11 jobs first, then
+        // k = 7, then k = 3), tile j % n_tiles; in round r the block takes job r * G + blockIdx.x (r even) or
+        // r * G + G - 1 - blockIdx.x (r odd), G = gridDim.x: the blocks that got the long jobs of one round get the short ones of
+        // the next.  The launch then takes about (all units) / G + one short job whatever its number of tiles is, instead of whole
+        // rounds of three-branch tiles (700 frames at batch 1 took as long as 1000).
+        // (Jobs DRAWN from a counter, longest first, were tried first: a returning atomic is waited for by the first vmcnt wait
+        //  behind it -- the next weight fragment, memory operations retire in order -- so every job paid the atomic's round
+        //  trip, 2-4 us on jobs of 12-50 us; profiles/r03_notes.md.)
+        const int n_jobs = 3 * n_tiles;
+        const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+        if (bx >= n_jobs) return;
+        // the problem of branch z, every field pinned to an SGPR before the selection (a plain select over kernel-argument
+        // structs becomes a per-lane table lookup: mrf_pair_f32_pf.h)
+        auto problem_of = [&](int z, const Tile& tn, bool valid) __attribute__((always_inline)) {
+            auto sel_i = [&](int v0, int v1, int v2) { int v = __builtin_amdgcn_readfirstlane(v0);
+                                                       if (z == 1) v = __builtin_amdgcn_readfirstlane(v1);
+                                                       if (z == 2) v = __builtin_amdgcn_readfirstlane(v2); return v; };
+            auto sel_p = [&](auto p0, auto p1, auto p2) { auto v = uniform_ptr_mrf(p0);
+                                                          if (z == 1) v = uniform_ptr_mrf(p1);
+                                                          if (z == 2) v = uniform_ptr_mrf(p2); return v; };
+            return NextJob{valid, tn.batch_off, tn.i0, tn.wvoff, sel_p(a.p[0].x, a.p[1].x, a.p[2].x), sel_p(a.p[0].wp, a.p[1].wp, a.p[2].wp),
+                           sel_i(a.p[0].ks, a.p[1].ks, a.p[2].ks), sel_i(a.p[0].dil, a.p[1].dil, a.p[2].dil),
+                           sel_i(a.p[0].pad_left, a.p[1].pad_left, a.p[2].pad_left)};
+        };
+        int round = 0;
+        int z = 2 - bx / n_tiles;
+        Tile t = make_tile(bx - (2 - z) * n_tiles);
+        {
+            const NextJob first = problem_of(z, t, true);
+            prologue(first.x, first.wp, first.ks, first.dil, first.pad_left, t);
+        }
+        for (;;) {
+            ++round;
+            const int job_next = round * G + ((round & 1) ? G - 1 - bx : bx);
+            const bool more = job_next < n_jobs;
+            const int zn = more ? 2 - job_next / n_tiles : z;
+            const Tile tn = make_tile(more ? job_next - (2 - zn) * n_tiles : 0);
+            const NextJob nxt = problem_of(zn, tn, more);
+            auto get_next = [&]() { return nxt; };
+            if (z == 2)      run_branch(std::integral_constant<int, KC>{}, I2{}, t, get_next);
+            else if (z == 1) run_branch(std::integral_constant<int, KB>{}, I1{}, t, get_next);
+            else             run_branch(std::integral_constant<int, KA>{}, I0{}, t, get_next);
+            if (!more) break;
+            z = zn;
+            t = tn;
+        }
     }
 #ifdef IRIS_MRF_BLOCKLOG
     if (tid == 0 && a.dbg) {
@@ -535,7 +614,7 @@ inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
 }
 
 // How a grouped MRF step is spread over the chip.
-struct MrfPlan { int MT; bool zpar; bool small; long long n_tiles; long long grid; int zb1, zb2; };
+struct MrfPlan { int MT; bool zpar; bool zdyn; bool small; long long n_tiles; long long grid; int zb1, zb2; };
 
 // the small-problem kernel (mrf_small_f32.h): 16 x 16 jobs on v_mfma_f32_16x16x4_f32, same bits
 inline bool mrf_small_applicable(const ConvLaunch& a, int nz);
@@ -544,33 +623,63 @@ inline hipError_t launch_mrf_small(ConvLaunch& a, int nz, hipStream_t stream);
 
 inline int mrf_cu_count() { return device_cu_count(); }
 
-// Tile-serial mode: a persistent grid of at most `per_cu` blocks per CU; every block runs the three branches of its
-// tiles (equal cost) and the grid is evened out so that every block walks the same number of tiles (+-1): 1000
-// tiles on 256 CUs x 2 -> 2 rounds -> 500 blocks of 2 tiles.  Time ~ rounds x 21 tap-units per 32 rows of tile.
-// One-branch-per-block mode (zpar, half-height tiles): jobs are (tile, branch) of 11 / 7 / 3 units; branch c gets
-// nb_c blocks which each walk ceil(tiles / nb_c) tiles, so the step takes max_c ceil(tiles / nb_c) x cost_c.  The
-// block counts are the ones that minimise that under nb_11 + nb_7 + nb_3 <= slots.  The mode with the smaller
-// estimate is taken (half-height tiles and zpar carry a few per cent overhead): zpar wins when there are few
-// tiles or their number falls between multiples of the slot count (T = 100 ... 400 frames at batch 1).
-// Small problems (a stage step with fewer 32-row tiles than the chip has room for): the 16 x 16-job kernel of
-// mrf_small_f32.h is taken when its estimate (MFMA work spread over all SIMDs, bounded below by its longest chain) is
-// clearly below the best of the modes above.
-// `force` (>= 0: the single-step test entry point, or the diagnostic build's IRIS_HIFIGAN_MRFPLAN) pins the mode:
-// 0 full-height tiles, 1 half-height tiles, 2 half-height + one branch per block, 3 the round-1 rule, 4 the small-problem kernel.
-inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
-    const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
-    const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", -1);
+// The modes, and how one is chosen (round 3: one timing model for all of them, calibrated on forced-plan sweeps over
+// 100 ... 2000 frames and batches 1 ... 32 -- profiles/r03_notes.md, tools/plan_sweep.py):
+//  * tile-serial (MT = 2 or 1): a persistent grid of at most `per_cu` blocks per CU; every block runs the three branches
+//    of its tiles (21 x MT tap-units each) and the grid is evened out so that every block walks the same number of tiles
+//    (+-1): 1000 tiles on 256 CUs x 2 -> 2 rounds -> 500 blocks of 2 tiles.
+//  * one branch per block, fixed ranges (zpar, MT = 1): branch c gets nb_c blocks which each walk ceil(tiles / nb_c) tiles;
+//    the block counts minimise max_c ceil(tiles / nb_c) x cost_c under nb_11 + nb_7 + nb_3 <= slots, or <= CUs (one block
+//    per CU) when the model prefers that.
+//  * (tile, branch) jobs in snake order (zdyn, MT = 2 or 1; two or more C_in chunks): min(3 x tiles, slots) blocks, see the
+//    kernel.  Takes about (all units) / slots + one short job whatever the number of tiles is, where the tile-serial mode pays
+//    whole rounds -- 700 frames at batch 1 took as long as 1000.
+//  * the small-problem kernel (mrf_small_f32.h: 16 x 16 jobs on v_mfma_f32_16x16x4_f32) when its estimate (MFMA work spread
+//    over all SIMDs, bounded below by its longest chain) is clearly below the best of the modes above.
+// The model: a block's chain is the tap-units it runs (x MT); blocks are dispatched in index order, so CU i hosts blocks
+// i, i + CUs, ...; two blocks on a CU share its matrix pipes -- while both run each advances one unit per time unit, a block
+// alone on its CU advances kLoneSpeed units (1.8: a lone wave per SIMD leaves its pipe idle between dependent MFMAs).  A CU
+// takes  shorter + (longer - shorter) / kLoneSpeed,  the launch the slowest CU.  Half-height tiles cost 6 % per unit (more
+// window per output row), the snake order 4 % (blocks end unevenly), fixed ranges 2 %.  Over the 66 measured (shape, stage)
+// cases the model's choice is within 2.5 % of the best forced plan, 0.1 % on average.
+// `force` (>= 0: the single-step test entry point, the diagnostic build's IRIS_HIFIGAN_MRFPLAN, or a calibration build's
+// IRIS_MRF_FORCE_PLAN) pins the mode: 0 full-height tiles, 1 half-height tiles, 2 half-height + one branch per block,
+// 3 the round-1 rule, 4 the small-problem kernel, 5 / 6 snake-ordered jobs at half / full tile height.
+constexpr double kLoneSpeed = 1.8, kHalfHeightCost = 1.06, kSnakeCost = 1.04, kFixedRangeCost = 1.02;
+
+inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_env, int per_cu) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     const int n_cu = mrf_cu_count();
-    const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
     const long long slots = (long long)n_cu * per_cu;
     const int n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     auto tiles = [&](int MT) { return (long long)((a.L_out + t.WT * MT * 32 - 1) / (t.WT * MT * 32)) * n_co_blk * a.B; };
-    // best split of the slots among the branches for n half-height tiles: smallest M with sum_c ceil(n / floor(M / cost_c)) <= slots
     static const int cost[3] = {3, 7, 11};            // branch 0, 1, 2
-    long long nb[3] = {1, 1, 1};
-    double zpar_units = 1e30;
     const long long n1 = tiles(1);
+    // time of the slowest CU; chain(i) = units of block i, CU c hosts blocks c, c + n_cu, ...
+    auto cu_time = [&](long long blocks, auto chain) -> double {
+        double worst = 0;
+        double c[8];
+        for (long long i = 0; i < blocks && i < n_cu; ++i) {
+            int k = 0;
+            for (long long j = i; j < blocks && k < 8; j += n_cu) c[k++] = chain(j);
+            for (int x = 1; x < k; ++x) for (int y = x; y > 0 && c[y] < c[y - 1]; --y) { const double tmp = c[y]; c[y] = c[y - 1]; c[y - 1] = tmp; }
+            double tcu = 0, prev = 0;
+            for (int x = 0; x < k; ++x) {                 // k - x blocks still running
+                const int m = k - x;
+                tcu += (c[x] - prev) * (m == 1 ? 1.0 / kLoneSpeed : 0.5 * m);
+                prev = c[x];
+            }
+            if (tcu > worst) worst = tcu;
+        }
+        return worst;
+    };
+    // tile-serial
+    auto serial_grid = [&](long long n) { long long g = n < slots ? n : slots; if (g < 1) g = 1; const long long r = (n + g - 1) / g; return (n + r - 1) / r; };
+    auto serial = [&](int MT) -> double {
+        const long long n = tiles(MT), g = serial_grid(n), rounds = (n + g - 1) / g, full = n - (rounds - 1) * g;
+        return cu_time(g, [&](long long i) { return (double)((i < full ? rounds : rounds - 1) * 21 * MT); }) * (MT == 1 ? kHalfHeightCost : 1.0);
+    };
+    // fixed ranges: smallest M with sum_c ceil(n / floor(M / cost_c)) <= limit
     auto split = [&](long long limit, long long (&out)[3]) -> double {
         double bestM = 1e30;
         for (int c = 0; c < 3; ++c)
@@ -589,67 +698,108 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
             }
         return bestM;
     };
-    // Two blocks on a CU share its four matrix pipes: a CU's time is the SUM of the chains of its blocks (block i and, when
-    // the grid has more blocks than CUs, block i + n_cu; blocks are dispatched heaviest branch first).  So a split over
-    // at most n_cu blocks with somewhat longer chains can beat the split that uses every slot (230-330 frames at batch 1,
-    // stage 0: 86 -> 69 us per step).
-    auto cu_units = [&](const long long (&x)[3]) -> double {
-        const long long total = x[0] + x[1] + x[2];
-        auto units = [&](long long idx) -> double {
-            const int c = idx < x[2] ? 2 : (idx < x[2] + x[1] ? 1 : 0);
-            return (double)((n1 + x[c] - 1) / x[c]) * cost[c];
-        };
-        double worst = 0;
-        for (long long i = 0; i < total && i < n_cu; ++i) {
-            const double t = units(i) + (i + n_cu < total ? units(i + n_cu) : 0.0);
-            if (t > worst) worst = t;
-        }
-        return worst;
+    auto ranges_time = [&](const long long (&x)[3]) -> double {      // blocks in dispatch order: branch 2, 1, 0
+        return cu_time(x[0] + x[1] + x[2], [&](long long i) {
+            const int c = i < x[2] ? 2 : (i < x[2] + x[1] ? 1 : 0);
+            return (double)(((n1 + x[c] - 1) / x[c]) * cost[c]);
+        }) * kHalfHeightCost * kFixedRangeCost;
     };
-    if (allow_zpar && n1 > 0) {
-        const double bestM = split(slots, nb);
-        zpar_units = bestM * 1.03 * 1.06;
-        if (bestM < 1e29 && nb[0] + nb[1] + nb[2] > n_cu && IRIS_DIAG_ENV("IRIS_HIFIGAN_ZPAR_ONE_PER_CU", IRIS_ZPAR_ONE_PER_CU_DEFAULT)) {
-            long long nb1[3] = {1, 1, 1};
-            const double M1 = split(n_cu, nb1);
-            // (0.85: a lone wave per SIMD does not keep its matrix pipe as busy as two that cover each other's waits --
-            //  with the chains level, 600 frames, the one-per-CU split was 5-12 % slower)
-            if (M1 < 1e29 && M1 < 0.85 * cu_units(nb)) { nb[0] = nb1[0]; nb[1] = nb1[1]; nb[2] = nb1[2]; }
+    long long nb[3] = {1, 1, 1};
+    double zpar_units = 1e30, zpar_chain = 1e30;
+    if (allow_zpar && n1 > 0 && (zpar_chain = split(slots, nb)) < 1e29) {
+        zpar_units = ranges_time(nb);
+        long long nb1[3] = {1, 1, 1};
+        if (nb[0] + nb[1] + nb[2] > n_cu && IRIS_DIAG_ENV("IRIS_HIFIGAN_ZPAR_ONE_PER_CU", IRIS_ZPAR_ONE_PER_CU_DEFAULT) && split(n_cu, nb1) < 1e29) {
+            const double u1 = ranges_time(nb1);
+            if (u1 < zpar_units) { zpar_units = u1; nb[0] = nb1[0]; nb[1] = nb1[1]; nb[2] = nb1[2]; }
         }
     }
+    // snake-ordered jobs: block b runs jobs r * G + (r even ? b : G - 1 - b); N(X) = how many of them have an index below X
+    auto snake = [&](int MT) -> double {
+        const long long n = tiles(MT), J = 3 * n, G = J < slots ? J : slots;
+        auto below = [&](long long X, long long b) {
+            long long cnt = 0;
+            for (int par = 0; par < 2; ++par) {
+                const long long off = par ? G - 1 - b : b;
+                const long long r = X > off ? (X - off + G - 1) / G : 0;       // rounds r' in [0, r) have r' * G + off < X
+                cnt += par ? r / 2 : (r + 1) / 2;
+            }
+            return cnt;
+        };
+        return cu_time(G, [&](long long b) {
+            const long long c11 = below(n, b), c7 = below(2 * n, b) - c11, c3 = below(J, b) - c11 - c7;
+            return (double)((11 * c11 + 7 * c7 + 3 * c3) * MT);
+        }) * (MT == 1 ? kHalfHeightCost : 1.0) * kSnakeCost;
+    };
     MrfPlan pl;
-    pl.MT = 2; pl.zpar = false; pl.small = false; pl.zb1 = pl.zb2 = 0;
+    pl.MT = 2; pl.zpar = false; pl.zdyn = false; pl.small = false; pl.zb1 = pl.zb2 = 0;
     const bool small_ok = allow_zpar && mrf_small_applicable(a, 3);
+    const bool zdyn_ok = allow_zpar && a.C_in >= 2 * t.CIC && n1 > 0;
     if (plan_env >= 0 && plan_env <= 2) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar && zpar_units < 1e29; }
+    else if (plan_env == 5 || plan_env == 6) { pl.MT = plan_env == 5 ? 1 : 2; pl.zpar = pl.zdyn = zdyn_ok; }
     else if (plan_env == 3) {
         if (4 * tiles(2) < 3 * slots) { pl.MT = 1; pl.zpar = allow_zpar && tiles(1) < n_cu && zpar_units < 1e29; }
     } else if (plan_env == 4) {
         pl.small = small_ok;
     } else {
-        auto serial = [&](int MT) { return (double)((tiles(MT) + slots - 1) / slots) * 21.0 * MT * (MT == 1 ? 1.03 : 1.0); };
         double best = serial(2);
-        if (serial(1) < 0.999 * best) { best = serial(1); pl.MT = 1; }
+        { const double u = serial(1); if (u < 0.999 * best) { best = u; pl.MT = 1; } }
         if (zpar_units < 0.999 * best) { best = zpar_units; pl.MT = 1; pl.zpar = true; }
-        // one unit = one tap of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles.
+        if (zdyn_ok && IRIS_DIAG_ENV("IRIS_HIFIGAN_ZDYN", IRIS_MRF_ZDYN_DEFAULT)) {
+            for (int MT = 2; MT >= 1; --MT) {
+                const double u = snake(MT);
+                if (u < 0.999 * best) { best = u; pl.MT = MT; pl.zpar = pl.zdyn = true; }
+            }
+        }
+        // The small-problem kernel is weighed as in round 2, against the longest CHAIN of the modes above (units of one tap
+        // of a 32-row x 32-channel wave tile = C/8 groups x 4 MFMAs x 64 cycles): that comparison was calibrated on
+        // 40 ... 282 frames and is kept as it was.
         // (A rule that also took the kernel for the C = 256 stage up to 2,600 rows was tried and removed: it rested on numbers
         // from the diagnostic build, whose persistent kernel is ~10 % slower; in the release build it won 5 % at 282 frames
         // and lost 10 % at 200 -- profiles/r02_notes.md.)
+        auto chain = [&](int MT) { return (double)((tiles(MT) + slots - 1) / slots) * 21.0 * MT * (MT == 1 ? 1.03 : 1.0); };
+        double longest = chain(2);
+        if (chain(1) < longest) longest = chain(1);
+        if (zpar_chain * 1.03 * 1.06 < longest) longest = zpar_chain * 1.03 * 1.06;
         if (small_ok && IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFSMALL", 1) &&
-            mrf_small_cycles(a, 3) < 0.9 * best * (double)a.C_in * 32.0) {
-            pl.small = true; pl.zpar = false; pl.MT = 1;
+            mrf_small_cycles(a, 3) < 0.9 * longest * (double)a.C_in * 32.0) {
+            pl.small = true; pl.zpar = pl.zdyn = false; pl.MT = 1;
         }
     }
     pl.n_tiles = tiles(pl.MT);
+    if (pl.zdyn) {
+        pl.grid = 3 * pl.n_tiles < slots ? 3 * pl.n_tiles : slots;
+        return pl;
+    }
     if (pl.zpar) {
         pl.zb1 = (int)nb[2]; pl.zb2 = (int)(nb[2] + nb[1]); pl.grid = nb[2] + nb[1] + nb[0];
         return pl;
     }
-    long long g = pl.n_tiles < slots ? pl.n_tiles : slots;
-    if (g < 1) g = 1;
-    const long long rounds = (pl.n_tiles + g - 1) / g;
-    g = (pl.n_tiles + rounds - 1) / rounds;
-    pl.grid = g;
+    pl.grid = serial_grid(pl.n_tiles);
     return pl;
+}
+
+// The plan of a (shape, mode) is the same in every forward: a few entries are remembered per thread.
+inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
+    const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
+    const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", IRIS_MRF_FORCE_PLAN);
+    const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
+#ifdef IRIS_MRF_DIAG
+    return mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);       // (environment switches may change between calls)
+#else
+    struct Entry { int key[8]; MrfPlan pl; bool used; };
+    static thread_local Entry cache[16] = {};
+    static thread_local int next = 0;
+    const int key[8] = {a.C_in, a.C_out, a.L_out, a.B, allow_zpar ? 1 : 0, plan_env, mrf_cu_count(), per_cu};
+    for (const Entry& e : cache)
+        if (e.used && memcmp(e.key, key, sizeof(key)) == 0) return e.pl;
+    Entry& e = cache[next];
+    next = (next + 1) % 16;
+    memcpy(e.key, key, sizeof(key));
+    e.pl = mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);
+    e.used = true;
+    return e.pl;
+#endif
 }
 
 inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int force_plan = -1) {
@@ -675,6 +825,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
     if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
     a.zb1 = pl.zb1; a.zb2 = pl.zb2;
+    a.zdyn = pl.zdyn ? 1 : 0;
     const long long n_tiles = pl.n_tiles, g = pl.grid;
     if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
@@ -686,11 +837,13 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
     do {                                                                                          \
         if (pl.MT == 2) {                                                                         \
-            if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true, false>);   \
-            else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, false>);  \
-        } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 11, 7, 3, true, false>);   \
-        else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, true>);   \
-        else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, false>);  \
+            if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, 2>);   \
+            else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true, 0>);   \
+            else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, 0>);  \
+        } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 11, 7, 3, true, 0>);   \
+        else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 2>);   \
+        else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 1>);   \
+        else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 0>);  \
     } while (0)
 #ifdef IRIS_MRF_BLOCKLOG
     static unsigned long long* blk_dev = nullptr;

@@ -166,13 +166,16 @@ def _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean):
     return status, ([t.cpu().numpy().transpose(0, 2, 1) for t in yd] if not mean else md.cpu().numpy().transpose(0, 2, 1))
 
 
-@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("plan", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("B,L,C,dils,use_res", MRF_STEP_CASES)
 def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
     """One conv step of the three ResBlock branches (k = 3/7/11; hifigan_pretrained.py:64-71) through the persistent
     MRF kernel, in the library's own plan (0), with full-height tiles (1), half-height tiles (2), one branch per
-    block (3) and through the small-problem kernel (4: 16 x 16 jobs on v_mfma_f32_16x16x4_f32), against the numpy
-    oracle's conv1d_np.  All plans run the same fmaf chains: they must agree bit for bit."""
+    block (3), through the small-problem kernel (4: 16 x 16 jobs on v_mfma_f32_16x16x4_f32) and with (tile, branch)
+    jobs drawn from a counter (5, 6: C >= 128), against the numpy oracle's conv1d_np.  All plans run the same fmaf
+    chains: they must agree bit for bit."""
+    if plan >= 5 and C < 128:
+        pytest.skip("the job mode needs two C_in chunks")
     rng = np.random.default_rng(C * 7 + L + plan)
     ks = (3, 7, 11)
     xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
@@ -191,6 +194,25 @@ def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
         _, auto = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, 0, mean=False)
         for j in range(3):
             assert np.array_equal(auto[j], got[j]), (j, plan)
+
+
+@pytest.mark.parametrize("B,L,C,dils", [(1, 6100, 256, (1, 1, 1)), (2, 7001, 128, (5, 5, 5)), (3, 1999, 256, (3, 3, 3))])
+def test_mrf_job_mode_agrees_bitwise_when_blocks_draw_many_jobs(lib, B, L, C, dils):
+    """Shapes with more (tile, branch) jobs than the chip has block slots, so that blocks do draw follow-up jobs of other
+    branches and tiles from the counter: plans 5 and 6 against plan 1 (checked against the oracle above), bit for bit."""
+    rng = np.random.default_rng(L + C)
+    ks = (3, 7, 11)
+    xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    ws = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    bs = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    rs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
+    status, want = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, 1, mean=False)
+    _check("op_mrf_step", status)
+    for plan in (5, 6, 0):
+        status, got = _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean=False)
+        _check("op_mrf_step", status)
+        for j in range(3):
+            assert np.array_equal(want[j], got[j]), (j, plan)
 
 
 @pytest.mark.parametrize("plan", [0, 1, 2])
