@@ -270,6 +270,16 @@ int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* con
                                       const float* const* w2_host, const float* const* b2_host, void* const* y_dev,
                                       int32_t n_branches, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
                                       float slope, void* stream);
+/* The LAST conv pair of a stage's three ResBlocks in bf16 storage, summed (hifigan_pretrained.py:64-71 and 131-137): one block
+ * runs the pair of all three branches on its rows, rounds each y_j to bf16 as the kernel above stores it, and writes ONE tensor
+ * [B, L, C]:  mean_f32 == 0: bf16(LeakyReLU(((y_0 + y_1) + y_2) * fp32(1/3))) -- bit for bit the operand the next
+ * ConvTranspose1d builds from the three tensors, which then reads one tensor and applies no activation;  mean_f32 != 0: the
+ * fp32 mean itself (conv_post's input after the last stage).  C = 32 or 64 (csrc/mrf_pair_bf16.h); mean_dev must not be an
+ * input.  Returns IRIS_HIFIGAN_UNSUPPORTED for other shapes. */
+int32_t iris_hifigan_op_mrf_pair_mean_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                           const float* const* w2_host, const float* const* b2_host, void* mean_dev,
+                                           int32_t mean_f32, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                           float slope, void* stream);
 /* the ResBlock Conv1d (C -> C, LeakyReLU on the input, optional residual) with fp32 tensors and split-bf16 products
  * (dtype IRIS_HIFIGAN_F32_SPLIT; C % 32 == 0): hifigan_pretrained.py:50-57,64-71. */
 int32_t iris_hifigan_op_conv1d_f32s(const float* x_dev, const float* w_host, const float* bias_host, const float* res_dev,

@@ -223,6 +223,9 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
     // where the running x of branch j lives: the fused pair kernel cannot work in place (a block's input window
     // overlaps its neighbours' output rows), so its output alternates between the y and the xt buffer of the branch
     const uint16_t* cur[IRIS_HIFIGAN_MAX_KERNELS] = {nullptr};
+    // the previous stage's last pair ran on the summing kernel (mrf_pair_bf16.h): its ONE output is the next layer's operand
+    const uint16_t* mean16 = nullptr;     // bf16(LeakyReLU(MRF mean)), for the next ConvTranspose1d
+    const float* mean32 = nullptr;        // the fp32 MRF mean of the last stage, for conv_post
     for (size_t i = 0; i < h->stages.size(); ++i) {
         const Stage& st = h->stages[i];
         const int L_out = L * st.rate;
@@ -234,8 +237,9 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
             a.p[0].wp = wb + l.w16_off; a.p[0].bias = blob + l.b_off;
             a.p[0].res = nullptr; a.p[0].y = ws + w.up;
             a.p[0].ks = taps; a.p[0].dil = 1; a.p[0].pad_left = taps - 1;
-            const int n_in = i == 0 ? 1 : nk;
+            const int n_in = i == 0 ? 1 : nk;       // (accounting L counts the reference's three branch tensors whatever was fused)
             if (i == 0) { a.p[0].x = ws + w.pre; a.in_act = IN_ACT_LRELU; }
+            else if (mean16) { a.p[0].x = mean16; a.in_act = IN_ACT_NONE; }      // already activated and rounded
             else {
                 a.in_act = IN_ACT_MRF_LRELU; a.n_mrf = nk;
                 for (int j = 0; j < nk; ++j) a.xmrf[j] = cur[j];
@@ -255,6 +259,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         const int nd = h->cfg.num_dilations[0];
         const double n_el = fB * L_out * st.C;
         for (int j = 0; j < nk; ++j) cur[j] = ws + w.up;
+        mean16 = nullptr;
         auto report_stop = [&]() -> int {
             if (until_flags) *until_flags = (cur[0] == ws + w.xt[0]) ? IRIS_HIFIGAN_UNTIL_X_IN_XT : 0;
             return prof.finish();
@@ -283,6 +288,31 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 const bool want_xt = stop.stage == (int)i && stop.step == 2 * m;
                 bool same_k = true;
                 for (int j = 0; j < nk; ++j) same_k = same_k && st.c1[j][m].k == st.c2[j][m].k && st.c2[j][m].dil == 1;
+                // The stage's LAST pair: one block runs the three branches of its rows and stores only the MRF mean, as the
+                // operand of the layer that follows (bf16, activated) or -- last stage -- as the fp32 mean conv_post takes.
+                // Not when the caller asked for a state of this stage (forward_until returns branch tensors).  The fp32 mean
+                // of the last stage is twice a bf16 tensor: it goes into `up` + y[0], adjacent in the workspace and both
+                // free while the pair reads xt[j] (an odd number of pairs per ResBlock; otherwise conv_post reads three).
+                if (m == nd - 1 && stop.stage != (int)i && same_k && nk == 3) {
+                    const bool last_stage = i + 1 == h->stages.size();
+                    bool room = true;
+                    if (last_stage) {
+                        room = w.y[0] >= w.up && (w.y[0] - w.up) * 2 >= (size_t)n_el * 2 && (w.y[0] - w.up) <= (size_t)n_el + 128;
+                        for (int j = 0; j < nk; ++j) room = room && cur[j] == ws + w.xt[j];
+                        post::ConvPostLaunch probe; memset(&probe, 0, sizeof(probe));       // conv_post must take one fp32 input of this shape
+                        probe.B = B; probe.L = L_out; probe.C = st.C; probe.n_in = 1; probe.k = h->post.k;
+                        room = room && h->post.C_in == st.C && post::conv_post_rows_ok(probe, false);
+                    }
+                    if (room && pair_sum_applicable(pa, nk, last_stage)) {
+                        void* dst = last_stage ? (void*)(ws + w.up) : (void*)pa.p[0].y;
+                        TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
+                        HIP_TRY(launch_pair_bf16_sum(pa, dst, last_stage, stream));
+                        TRY(prof.end());
+                        if (last_stage) mean32 = (const float*)dst; else mean16 = (const uint16_t*)dst;
+                        for (int j = 0; j < nk; ++j) cur[j] = nullptr;
+                        continue;
+                    }
+                }
                 if (!want_xt && same_k && pair_applicable(pa, nk)) {
                     TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
 #ifdef IRIS_MRF_DIAG
@@ -339,7 +369,12 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
         ar.n_in = nk; ar.inv_n = 1.0f / (float)nk;
         ar.w = blob + l.w_off; ar.bias = blob + l.b_off; ar.y = (float*)wav_dev;
         ar.B = B; ar.L = L; ar.C = C; ar.k = l.k; ar.slope = slope;
-        if (post::conv_post_rows_ok(ar, true)) {
+        if (mean32) {
+            // the summing pair left the fp32 mean: conv_post as in the fp32 path (one fp32 input, LeakyReLU in fp32)
+            ar.x[0] = mean32; ar.n_in = 1;
+            if (!post::conv_post_rows_ok(ar, false)) return fail(IRIS_HIFIGAN_UNSUPPORTED, "conv_post: shape not supported behind the summing pair");
+            HIP_TRY(post::launch_conv_post_t<false>(ar, stream));
+        } else if (post::conv_post_rows_ok(ar, true)) {
             // 16-byte staging, batch folded into the grid (conv_post.h); same arithmetic as the kernel below, which takes
             // the shapes this one cannot (other channel counts; a single item of 2^31 bytes or more)
             HIP_TRY(post::launch_conv_post_t<true>(ar, stream));
@@ -445,6 +480,48 @@ int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* con
     else
 #endif
     HIP_TRY(launch_pair_bf16(a, n_branches, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return IRIS_HIFIGAN_OK;
+    IRIS_ABI_END
+}
+
+int32_t iris_hifigan_op_mrf_pair_mean_bf16(const void* const* x_dev, const float* const* w1_host, const float* const* b1_host,
+                                           const float* const* w2_host, const float* const* b2_host, void* mean_dev,
+                                           int32_t mean_f32, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,
+                                           float slope, void* stream_) {
+    IRIS_ABI_BEGIN
+    using namespace iris;
+    using namespace iris::b16;
+    if (!x_dev || !w1_host || !b1_host || !w2_host || !b2_host || !mean_dev || !k || !dil)
+        return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL argument");
+    if (B < 1 || L < 1 || C < 1 || B > 65535) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad mrf_pair shape");
+    const int nz = 3;
+    hipStream_t stream = (hipStream_t)stream_;
+    PairLaunch a; memset(&a, 0, sizeof(a));
+    DevBytes w1b[kMaxGroup], w2b[kMaxGroup], b1b[kMaxGroup], b2b[kMaxGroup];
+    for (int j = 0; j < nz; ++j) {
+        if (!x_dev[j] || !w1_host[j] || !b1_host[j] || !w2_host[j] || !b2_host[j])
+            return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL branch argument");
+        if (k[j] < 1 || !(k[j] & 1) || dil[j] < 1) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "bad kernel size / dilation");
+        if (x_dev[j] == mean_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "the mean must not overwrite an input");
+        a.p[j].ks = k[j]; a.p[j].dil = dil[j];
+    }
+    a.B = B; a.L = L; a.C = C; a.slope = slope;
+    if (!pair_sum_applicable(a, nz, mean_f32 != 0))
+        return fail(IRIS_HIFIGAN_UNSUPPORTED, "the summing pair kernel takes C = 32 or 64, three branches and windows up to 64 KB");
+    for (int j = 0; j < nz; ++j) {
+        std::vector<uint16_t> packed(packed_conv1d_halfs(C, C, k[j]));
+        pack_conv1d_bf16(w1_host[j], C, C, k[j], packed.data());
+        HIP_TRY(w1b[j].upload(packed.data(), packed.size() * sizeof(uint16_t)));
+        pack_conv1d_bf16(w2_host[j], C, C, k[j], packed.data());
+        HIP_TRY(w2b[j].upload(packed.data(), packed.size() * sizeof(uint16_t)));
+        HIP_TRY(b1b[j].upload(b1_host[j], sizeof(float) * C));
+        HIP_TRY(b2b[j].upload(b2_host[j], sizeof(float) * C));
+        a.p[j].x = (const uint16_t*)x_dev[j]; a.p[j].y = nullptr;
+        a.p[j].w1 = w1b[j].p; a.p[j].w2 = w2b[j].p;
+        a.p[j].b1 = (const float*)b1b[j].p; a.p[j].b2 = (const float*)b2b[j].p;
+    }
+    HIP_TRY(launch_pair_bf16_sum(a, mean_dev, mean_f32 != 0, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
     IRIS_ABI_END

@@ -32,6 +32,12 @@ namespace iris {
 #define IRIS_MRF_ABLATE(a) 0
 #endif
 
+#ifndef IRIS_MRF_RING_MT1
+#define IRIS_MRF_RING_MT1 4              // weight fragments in flight (groups ahead), half-height / full-height tiles (C >= 64)
+#endif
+#ifndef IRIS_MRF_RING_MT2
+#define IRIS_MRF_RING_MT2 4
+#endif
 #ifndef IRIS_MRF_FORCE_PLAN
 #define IRIS_MRF_FORCE_PLAN (-1)         // calibration builds (make relvariant EXTRA=-DIRIS_MRF_FORCE_PLAN=n): every launch in plan n
 #endif
@@ -834,16 +840,16 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         auto kfn = __VA_ARGS__;                                                                   \
         { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
     } while (0)
-#define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_)                                                       \
+#define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_, D1_, D2_)                                                       \
     do {                                                                                          \
         if (pl.MT == 2) {                                                                         \
-            if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, 2>);   \
-            else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 11, 7, 3, true, 0>);   \
-            else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, 4, 3, 7, 11, false, 0>);  \
-        } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 11, 7, 3, true, 0>);   \
-        else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 2>);   \
-        else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 1>);   \
-        else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, 4, 3, 7, 11, false, 0>);  \
+            if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 2>);   \
+            else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 11, 7, 3, true, 0>);   \
+            else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 0>);  \
+        } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 11, 7, 3, true, 0>);   \
+        else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 2>);   \
+        else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 1>);   \
+        else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 0>);  \
     } while (0)
 #ifdef IRIS_MRF_BLOCKLOG
     static unsigned long long* blk_dev = nullptr;
@@ -857,9 +863,9 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     (void)hipMemsetAsync(dbg_dev, 0, 16 * sizeof(unsigned long long), stream);
     a.dbg = dbg_dev;
 #endif
-    if (t.WT == 4)          IRIS_MRF_LAUNCH_DB(4, 1, 32);     // C <= 32 (mrf_kernel_applicable: CIC == 32 there)
-    else if (t.WT == 2)     IRIS_MRF_LAUNCH_DB(2, 2, 64);
-    else                    IRIS_MRF_LAUNCH_DB(1, 4, 64);
+    if (t.WT == 4)          IRIS_MRF_LAUNCH_DB(4, 1, 32, 4, 4);     // C <= 32 (mrf_kernel_applicable: CIC == 32 there)
+    else if (t.WT == 2)     IRIS_MRF_LAUNCH_DB(2, 2, 64, IRIS_MRF_RING_MT1, 4);
+    else                    IRIS_MRF_LAUNCH_DB(1, 4, 64, IRIS_MRF_RING_MT1, IRIS_MRF_RING_MT2);
 #ifdef IRIS_MRF_STAMPS
     {   // diagnostic build: synchronous read-back of the per-wave cycle shares
         unsigned long long h[16];

@@ -30,6 +30,22 @@
 #include <stdio.h>
 #include "conv_mfma_bf16.h"
 
+#ifndef IRIS_B16_PAIR_SUM_DEFAULT
+#define IRIS_B16_PAIR_SUM_DEFAULT 1      // the stage's last pair on the summing kernel (A/B builds: 0)
+#endif
+#ifndef IRIS_B16_SUM32_MT
+#define IRIS_B16_SUM32_MT 3              // summing kernel, C = 32: 4 x MT x 32 rows per block
+#endif
+#ifndef IRIS_B16_SUM64_MT
+#define IRIS_B16_SUM64_MT 3              // C = 64: 2 x MT x 32 rows
+#endif
+#ifndef IRIS_B16_SUM32_MINB
+#define IRIS_B16_SUM32_MINB 2            // blocks per CU the summing kernel is compiled for
+#endif
+#ifndef IRIS_B16_SUM64_MINB
+#define IRIS_B16_SUM64_MINB 2
+#endif
+
 namespace iris {
 namespace b16 {
 
@@ -53,6 +69,10 @@ struct PairLaunch {
     int n_jobs;           // tiles x branches (tiles = ceil(L / smallest T_OUT))
     int jobs_per_xcd;     // ceil(n_jobs / 8)
     int bias_off;         // persistent kernel: byte offset of the bias table in LDS
+    void* sum_y;          // summing kernel: the ONE output, [B, L, C]: bf16(LeakyReLU(mean_j y_j)) -- the operand the next
+                          // ConvTranspose1d stages -- or, sum_f32 != 0, the fp32 mean itself (conv_post's input)
+    int sum_f32;
+    float inv_n;          // fp32(1 / nz)
     int ablate;           // diagnostics only: 1 no staging loads, 2 no MFMA loops, 4 no stores, 8 no residual loads
     unsigned long long* dbg;  // diagnostics only (stamp builds): per-segment cycle sums, else nullptr
 };
@@ -339,6 +359,242 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
 #undef PAIR_STAMP
 }
 
+// ---- the stage's LAST pair, summing: a block runs the pair of ALL THREE branches on its rows and stores only the MRF mean ----
+// hifigan_pretrained.py:131-137: xs = rb0(x); xs += rb1(x); xs += rb2(x); x = xs / 3, followed by LeakyReLU at the head of the
+// next layer.  With separate (tile, branch) blocks the three y_j go to HBM and the next ConvTranspose1d (or conv_post) reads
+// all three -- at bf16 those layers are pure traffic (configs[2]: 0.97 + 0.17 ms of a 10.7 ms step).  Here a block keeps
+// sum_j float(y_j) in registers (y_j rounded to bf16 exactly as the separate kernel stores it, added in the order 0, 1, 2)
+// and stores  bf16(LeakyReLU(((y0 + y1) + y2 + 0) * inv_n))  -- bit for bit the operand stage_window() builds from the three
+// tensors (conv_mfma_bf16.h) -- so the consumer reads ONE tensor and applies no activation; for the last stage it stores the
+// fp32 mean instead, which conv_post takes as it takes the fp32 path's (conv_post.h, n_in = 1).  Writes drop from three
+// tensors to one, the consumer's reads from three to one.
+// All branches use the rows [o0, o0 + T_OUT) with T_OUT = M - (k_max - 1): the smaller kernels throw away a few more rows.
+// The price: accumulators AND the sum live at once (2 x MT x NT x 16 registers), so tiles are smaller or blocks fewer than in
+// the kernel above, and a block is three pairs long.
+template <int WT, int WC, int MT, int NT, int C, int MINB>
+__global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_sum_kernel(const PairLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_pair[];
+    char* lds = lds_pair;
+    static_assert(WT * WC == 4 && WC * NT * 32 == C, "a block owns all C channels");
+    constexpr int SB = C * 2 + 16;
+    constexpr int M = WT * MT * 32;
+    constexpr int PPR = C / 8;
+    constexpr int NQ = ((M + kPairSpanMax) * PPR + 255) / 256;
+    constexpr int D = 4;
+    constexpr int NZ = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = wave / WC, wc = wave - wt * WC;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = xcd * a.jobs_per_xcd + slot;             // (n_jobs = tiles here)
+    if (tile >= a.n_jobs) return;
+    int kmax = a.p[0].ks;
+    if (a.p[1].ks > kmax) kmax = a.p[1].ks;
+    if (a.p[2].ks > kmax) kmax = a.p[2].ks;
+    const int T_OUT = M - (kmax - 1);
+    const int o0 = tile * T_OUT;
+    const int L = a.L;
+    if (o0 >= L) return;
+    const int b = blockIdx.y;
+    const int ct0 = wc * NT;
+    const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 2u;
+    const size_t item = (size_t)b * L * C;
+    const unsigned q_bytes = (unsigned)a.n_ct * 1024u;
+    const unsigned tap_bytes = (unsigned)a.Qp * q_bytes;
+    const unsigned wvoff = (unsigned)ct0 * 1024u + (unsigned)lane * 16u;
+    const char* a_lane = lds + (wt * MT * 32 + lo) * SB + hi * 16;
+
+    // epilogue geometry (the same for the three branches)
+    constexpr int RS = NT * 32 * 4 + 16;
+    constexpr int PPRO = NT * 4;
+    constexpr int NP = 2 * NT;
+    unsigned pvoff[MT][NP];
+    int pscr[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int q = j * 64 + lane;
+        const int row_l = q / PPRO, pc = q - row_l * PPRO;
+        pscr[j] = row_l * RS + pc * 32;
+        const int co = ct0 * 32 + 8 * pc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int im = (wt * MT + m) * 32 + row_l;
+            const int o = o0 + im;
+            pvoff[m][j] = (im < T_OUT && o < L) ? (unsigned)(o * C + co) * 2u : kOob;
+        }
+    }
+    float sum[MT][NP][8];
+    f32x16 acc[MT][NT];
+    auto load_bias = [&](f32x4 (&bias4)[NT][4], const float* bptr) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[nt][g] = *reinterpret_cast<const f32x4*>(bptr + (ct0 + nt) * 32 + 8 * g + 4 * hi);
+    };
+    auto init_acc = [&](const f32x4 (&bias4)[NT][4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nt][r] = bias4[nt][r >> 2][r & 3];
+    };
+    char* scr = lds + wave * (32 * RS);
+
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) {
+        // (a distinct marker per branch keeps hipcc from merging the three bodies' heads across the unrolled loop)
+        asm volatile("; bf16 summing pair, branch %0" :: "n"(z) : "memory");
+        const PairProblem& p = a.p[z];                     // constant index: stays in the kernel-argument segment
+        const int ks = p.ks, dil = p.dil;
+        const int h2 = (ks - 1) / 2, h1 = dil * (ks - 1) / 2;
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x + item, tensor_bytes);
+        const __amdgpu_buffer_rsrc_t wr1 = make_rsrc(p.w1, (unsigned)ks * tap_bytes);
+        const __amdgpu_buffer_rsrc_t wr2 = make_rsrc(p.w2, (unsigned)ks * tap_bytes);
+        if (z > 0) __syncthreads();                        // the previous branch's epilogue scratch aliases the window
+        // ---- 1. bias1, conv1's first weight fragments, the x window ----
+        f32x4 bias4[NT][4];
+        load_bias(bias4, p.b1);
+        u32x4 wv[D][NT];
+        ring_request<NT, C, D>(wv, wr1, wvoff, q_bytes, tap_bytes);
+        {
+            const int in_row0 = o0 - h2 - h1, R = M + (ks - 1) * dil, total = R * PPR;
+            u32x4 v[NQ];
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int idx = u * 256 + (int)threadIdx.x;
+                const int r = idx / PPR, pc = idx & (PPR - 1);
+                const int row = in_row0 + r;
+                const bool ok = idx < total && row >= 0 && row < L;
+                v[u] = buf_load4(xr, ok ? (unsigned)(row * C + 8 * pc) * 2u : kOob, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int idx = u * 256 + (int)threadIdx.x;
+                const int r = idx / PPR, pc = idx & (PPR - 1);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned w = v[u][e];
+                    o[e] = pack_bf2(lrelu_max(bf_lo(w), a.slope), lrelu_max(bf_hi(w), a.slope));
+                }
+                if (idx < total) *reinterpret_cast<u32x4*>(lds + r * SB + pc * 16) = o;
+            }
+        }
+        __syncthreads();
+        // ---- 2. conv1 ----
+        init_acc(bias4);
+        ring_mma_loop<MT, NT, C, D>(acc, wv, a_lane, dil * SB, wr1, wvoff, q_bytes, tap_bytes, ks);
+        ring_request<NT, C, D>(wv, wr2, wvoff, q_bytes, tap_bytes);
+        load_bias(bias4, p.b2);
+        __syncthreads();
+        // ---- 3. xt -> LDS ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row_l = (wt * MT + m) * 32 + lo;
+            const int row_g = o0 - h2 + row_l;
+            const unsigned keep = (row_g >= 0 && row_g < L) ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 o;
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const unsigned t = pack_bf2(acc[m][nt][4 * g + 2 * e2], acc[m][nt][4 * g + 2 * e2 + 1]);
+                        o[e2] = pack_bf2(lrelu_max(bf_lo(t), a.slope), lrelu_max(bf_hi(t), a.slope)) & keep;
+                    }
+                    *reinterpret_cast<u32x2*>(lds + row_l * SB + ((ct0 + nt) * 32 + 8 * g + 4 * hi) * 2) = o;
+                }
+        }
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.x + item, tensor_bytes);
+        constexpr int RB = (MT * NT > 3) ? 1 : 2;         // residual buffers: one when registers are short (accumulators + sum)
+        u32x4 resv[RB][NP];
+        if (RB == 2) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) resv[0][j] = buf_load4(rr, pvoff[0][j], 0);
+        }
+        __syncthreads();
+        // ---- 4. conv2 ----
+        init_acc(bias4);
+        ring_mma_loop<MT, NT, C, D>(acc, wv, a_lane, SB, wr2, wvoff, q_bytes, tap_bytes, ks);
+        __syncthreads();
+        // ---- 5. epilogue: y_j = bf16(acc + x_j) as the separate kernel stores it; sum += float(y_j) ----
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (RB == 2) {
+                if (m + 1 < MT) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) resv[(m + 1) % RB][j] = buf_load4(rr, pvoff[m + 1][j], 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) resv[0][j] = buf_load4(rr, pvoff[m][j], 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[m][nt][4 * g + e];
+                    *reinterpret_cast<f32x4*>(scr + lo * RS + (nt * 32 + 8 * g + 4 * hi) * 4) = v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(scr + pscr[j]);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + pscr[j] + 16);
+                const u32x4 rv = resv[m % RB][j];
+                unsigned yp[4];
+                yp[0] = pack_bf2(lo4[0] + bf_lo(rv[0]), lo4[1] + bf_hi(rv[0]));
+                yp[1] = pack_bf2(lo4[2] + bf_lo(rv[1]), lo4[3] + bf_hi(rv[1]));
+                yp[2] = pack_bf2(hi4[0] + bf_lo(rv[2]), hi4[1] + bf_hi(rv[2]));
+                yp[3] = pack_bf2(hi4[2] + bf_lo(rv[3]), hi4[3] + bf_hi(rv[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (z == 0) { sum[m][j][2 * e] = bf_lo(yp[e]); sum[m][j][2 * e + 1] = bf_hi(yp[e]); }
+                    else        { sum[m][j][2 * e] = sum[m][j][2 * e] + bf_lo(yp[e]); sum[m][j][2 * e + 1] = sum[m][j][2 * e + 1] + bf_hi(yp[e]); }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- the mean.  "+ 0.f": the consumer's three-tensor staging adds a fourth, absent input (reads as 0) ----
+    if (a.sum_f32) {
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc((float*)a.sum_y + item, tensor_bytes * 2u);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                u32x4 o0v, o1v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0v[e] = __builtin_bit_cast(unsigned, (sum[m][j][e] + 0.f) * a.inv_n);
+                    o1v[e] = __builtin_bit_cast(unsigned, (sum[m][j][4 + e] + 0.f) * a.inv_n);
+                }
+                const unsigned vo = pvoff[m][j] == kOob ? kOob : pvoff[m][j] * 2u;
+                __builtin_amdgcn_raw_buffer_store_b128(o0v, yr, (int)vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1v, yr, (int)vo, 16, 0);
+            }
+    } else {
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc((uint16_t*)a.sum_y + item, tensor_bytes);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf2(lrelu1((sum[m][j][2 * e] + 0.f) * a.inv_n, a.slope), lrelu1((sum[m][j][2 * e + 1] + 0.f) * a.inv_n, a.slope));
+                __builtin_amdgcn_raw_buffer_store_b128(o, yr, (int)pvoff[m][j], 0, 0);
+            }
+    }
+}
+
 // ---- launch ----------------------------------------------------------------------------------------
 struct PairTile { int WT, WC, MT, NT, MINB, M; };
 
@@ -440,6 +696,71 @@ inline hipError_t launch_pair_bf16(PairLaunch& a, int nz, hipStream_t stream) {
     IRIS_PAIR_CASE(2, 2, 2, 2, 128, 3)
     IRIS_PAIR_CASE(2, 2, 3, 2, 128, 2)
 #undef IRIS_PAIR_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---- the summing kernel's tiles and launch ----------------------------------------------------------------
+// Accumulators and the sum are live together: 2 x MT x NT x 16 registers, so two blocks per CU.
+inline bool pair_sum_tile_for(int C, PairTile* t) {
+    if (C == 32)  { *t = PairTile{4, 1, IRIS_B16_SUM32_MT, 1, IRIS_B16_SUM32_MINB, 4 * IRIS_B16_SUM32_MT * 32}; return true; }
+    if (C == 64)  { *t = PairTile{2, 2, IRIS_B16_SUM64_MT, 1, IRIS_B16_SUM64_MINB, 2 * IRIS_B16_SUM64_MT * 32}; return true; }
+    // (C = 128 -- 128 rows x 128 channels: 64 + 64 accumulator and sum registers next to a 32-register weight ring -- spills ~95
+    //  registers at two blocks per CU and is left to the three-tensor path)
+    return false;
+}
+
+// True when the stage's last pair can run on the summing kernel: three branches of equal kernel size per pair, shapes the
+// pair kernel takes, and -- for the fp32 mean -- an item below 2^31 bytes at four bytes per element.
+inline bool pair_sum_applicable(const PairLaunch& a, int nz, bool f32_out) {
+    PairTile t;
+    if (nz != 3 || !pair_sum_tile_for(a.C, &t)) return false;
+    if (!(a.slope >= 0.f && a.slope <= 1.f)) return false;
+    if ((double)a.L * a.C * (f32_out ? 4.0 : 2.0) >= 2147483648.0) return false;
+    for (int j = 0; j < nz; ++j) {
+        const int ks = a.p[j].ks, d = a.p[j].dil;
+        if (ks < 1 || !(ks & 1) || d < 1) return false;
+        if (ks - 1 >= t.M / 2) return false;
+        if ((ks - 1) * d > kPairSpanMax) return false;
+        if ((size_t)(t.M + (ks - 1) * d) * (a.C * 2 + 16) > 66 * 1024) return false;
+    }
+    return IRIS_DIAG_ENV("IRIS_B16_PAIR_SUM", IRIS_B16_PAIR_SUM_DEFAULT) != 0;
+}
+
+inline hipError_t launch_pair_bf16_sum(PairLaunch& a, void* sum_y, bool f32_out, hipStream_t stream) {
+    PairTile t;
+    if (!pair_sum_tile_for(a.C, &t) || !sum_y) return hipErrorInvalidValue;
+    for (int j = 0; j < 3; ++j)
+        if ((const void*)a.p[j].x == sum_y) return hipErrorInvalidValue;     // never in place (and the fp32 mean spans two buffers: the caller checks)
+    a.nz = 3;
+    a.Qp = packed_qsteps(a.C);
+    a.n_ct = packed_cotiles(a.C);
+    a.ablate = 0;
+    a.dbg = nullptr;
+    a.sum_y = sum_y; a.sum_f32 = f32_out ? 1 : 0; a.inv_n = 1.0f / 3.0f;
+    int span = 0, kmax = 1;
+    for (int j = 0; j < 3; ++j) {
+        const int s = (a.p[j].ks - 1) * a.p[j].dil;
+        if (s > span) span = s;
+        if (a.p[j].ks > kmax) kmax = a.p[j].ks;
+    }
+    const int t_out = t.M - (kmax - 1);
+    const long long tiles = (a.L + t_out - 1) / t_out;
+    if (tiles > 0x3fffffffLL || a.B > 65535) return hipErrorInvalidValue;
+    a.n_jobs = (int)tiles;
+    a.jobs_per_xcd = (int)((tiles + 7) / 8);
+    const size_t window_bytes = (size_t)(t.M + span) * (a.C * 2 + 16);
+    const size_t scratch_bytes = (size_t)4 * 32 * (t.NT * 32 * 4 + 16);
+    const size_t lds_bytes = window_bytes > scratch_bytes ? window_bytes : scratch_bytes;
+    dim3 grid((unsigned)(a.jobs_per_xcd * 8), (unsigned)a.B, 1u), block(256);
+#define IRIS_PAIR_SUM_CASE(WT_, WC_, MT_, NT_, C_, MINB_)                                                    \
+    if (a.C == C_ && t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.MINB == MINB_) {        \
+        auto kfn = mrf_pair_bf16_sum_kernel<WT_, WC_, MT_, NT_, C_, MINB_>;                                  \
+        { const hipError_t e__ = ::iris::launch_kernel_named("mrf_pair_bf16_sum_kernel", kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
+        return hipSuccess;                                                                                   \
+    }
+    IRIS_PAIR_SUM_CASE(4, 1, IRIS_B16_SUM32_MT, 1, 32, IRIS_B16_SUM32_MINB)
+    IRIS_PAIR_SUM_CASE(2, 2, IRIS_B16_SUM64_MT, 1, 64, IRIS_B16_SUM64_MINB)
+#undef IRIS_PAIR_SUM_CASE
     return hipErrorInvalidValue;
 }
 

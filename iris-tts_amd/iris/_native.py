@@ -138,6 +138,8 @@ SYMBOLS = {
                                        _c.POINTER(_vp), _vp, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _i32, _vp]),
     "iris_hifigan_op_mrf_pair_bf16": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
                                             _c.POINTER(_vp), _i32, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
+    "iris_hifigan_op_mrf_pair_mean_bf16": (_i32, [_c.POINTER(_vp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp), _c.POINTER(_fp),
+                                                 _vp, _i32, _i32, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32), _f, _vp]),
     "iris_hifigan_op_conv1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv_transpose1d_bf16": (_i32, [_vp, _fp, _fp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
     "iris_hifigan_op_conv1d_f32s": (_i32, [_vp, _fp, _fp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp]),

@@ -172,6 +172,66 @@ def test_bf16_fused_pair_equals_separate_layers_and_oracle(B, L, C, dils):
             assert (np.abs(got - _r16(want.astype(np.float32))) == 0).mean() > 0.9
 
 
+MEAN_PAIR_CASES = [
+    # (B, L, C, dils): tile edges (T_OUT = M - 10 for all three branches: M = 384 at C = 32, 192 at C = 64), short inputs, ragged tails
+    (1, 1, 32, (1, 1, 1)), (2, 9, 32, (5, 5, 5)), (1, 373, 32, (3, 3, 3)), (1, 374, 32, (5, 5, 5)), (1, 375, 32, (1, 1, 1)),
+    (2, 1531, 32, (5, 5, 5)), (1, 20000, 32, (3, 3, 3)),
+    (1, 7, 64, (5, 5, 5)), (1, 181, 64, (1, 1, 1)), (1, 182, 64, (3, 3, 3)), (1, 183, 64, (5, 5, 5)), (2, 777, 64, (5, 5, 5)),
+    (1, 9000, 64, (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("mean_f32", [0, 1])
+@pytest.mark.parametrize("B,L,C,dils", MEAN_PAIR_CASES)
+def test_bf16_summing_pair_equals_three_tensor_path(B, L, C, dils, mean_f32):
+    """The stage's last pair on the summing kernel (hifigan_pretrained.py:64-71, 131-137): ONE output that must be, bit for
+    bit, what the consumer would build from the three y_j of the per-branch kernel -- bf16(LeakyReLU(((y0 + y1) + y2) * fp32(1/3)))
+    for the next ConvTranspose1d, or that mean in fp32 for conv_post."""
+    from iris import _native
+    lib = _native.load()
+    rng = np.random.default_rng(C + L + 17)
+    ks = (3, 7, 11)
+    xs = [_r16(rng.standard_normal((B, C, L)).astype(np.float32)) for _ in ks]
+    w1 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    w2 = [(rng.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32) for k in ks]
+    b1 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    b2 = [rng.standard_normal(C).astype(np.float32) for _ in ks]
+    xd = [_bf16_cl(x) for x in xs]
+    yd = [torch.full((B, L, C), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in ks]
+    vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
+    args = (fp3(*[_fp(w) for w in w1]), fp3(*[_fp(b) for b in b1]), fp3(*[_fp(w) for w in w2]), fp3(*[_fp(b) for b in b2]))
+    _native.check("op_mrf_pair_bf16", lib.iris_hifigan_op_mrf_pair_bf16(
+        vp3(*[t.data_ptr() for t in xd]), *args, vp3(*[t.data_ptr() for t in yd]),
+        3, B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None))
+    md = torch.full((B, L, C), float("nan"), dtype=torch.float32 if mean_f32 else torch.bfloat16, device="cuda")
+    _native.check("op_mrf_pair_mean_bf16", lib.iris_hifigan_op_mrf_pair_mean_bf16(
+        vp3(*[t.data_ptr() for t in xd]), *args, md.data_ptr(), mean_f32,
+        B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, None))
+    y = [t.float().cpu() for t in yd]
+    mean = (((y[0] + y[1]) + y[2]) + 0.0) * torch.tensor(1.0 / 3.0, dtype=torch.float32)
+    if mean_f32:
+        want = mean
+    else:
+        want = torch.where(mean > 0, mean, mean * torch.tensor(0.1, dtype=torch.float32)).to(torch.bfloat16)
+    got = md.cpu()
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want), int((got != want).sum())
+
+
+def test_bf16_summing_pair_rejects_other_channel_counts():
+    from iris import _native
+    lib = _native.load()
+    z = torch.zeros((1, 8, 128), dtype=torch.bfloat16, device="cuda")
+    m = torch.zeros((1, 8, 128), dtype=torch.bfloat16, device="cuda")
+    w = np.zeros((128, 128, 3), np.float32)
+    b = np.zeros(128, np.float32)
+    vp3, fp3 = ctypes.c_void_p * 3, ctypes.POINTER(ctypes.c_float) * 3
+    rc = lib.iris_hifigan_op_mrf_pair_mean_bf16(vp3(*[z.data_ptr()] * 3), fp3(*[_fp(w)] * 3), fp3(*[_fp(b)] * 3), fp3(*[_fp(w)] * 3),
+                                                fp3(*[_fp(b)] * 3), m.data_ptr(), 0, 1, 8, 128, (ctypes.c_int32 * 3)(3, 3, 3),
+                                                (ctypes.c_int32 * 3)(1, 1, 1), 0.1, None)
+    assert rc == 4      # IRIS_HIFIGAN_UNSUPPORTED
+
+
 def test_bf16_fused_pair_rejects_other_channel_counts():
     from iris import _native
     lib = _native.load()

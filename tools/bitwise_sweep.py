@@ -1,5 +1,5 @@
 """Compares the waveforms of two builds of the library bitwise over 63 (batch, frames) shapes (diagnostics: every launch
-plan and fused kernel must produce the same bits).  usage: python tools/bitwise_sweep.py <other libiris_hifigan_*.so>"""
+plan and fused kernel must produce the same bits).  usage: python tools/bitwise_sweep.py <other libiris_hifigan_*.so> [f32|bf16]"""
 import os, subprocess, sys, json
 import numpy as np
 shapes = [(1, t) for t in (1, 2, 3, 5, 7, 13, 31, 40, 50, 63, 64, 65, 77, 99, 100, 117, 118, 119, 127, 128, 129, 150, 199, 230, 257, 282, 301, 333, 390, 391, 450)] + \
@@ -10,11 +10,11 @@ import sys, json, hashlib, torch
 sys.path.insert(0, "iris-tts_amd")
 from iris._engine import GeneratorEngine
 from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
-shapes = json.loads(sys.argv[1])
+shapes = json.loads(sys.argv[1]); dtype = sys.argv[2]
 cfg = GeneratorConfig(); eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=11, gain=1.15, post_gain=12.0), torch.device("cuda", 0))
 out = {}
 for B, T in shapes:
-    y = eng.forward(torch.from_numpy(seeded_mel(100 + T, B, T)).cuda())
+    y = eng.forward(torch.from_numpy(seeded_mel(100 + T, B, T)).cuda(), dtype=dtype)
     out[f"{B}x{T}"] = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()
 print(json.dumps(out))
 '''
@@ -23,7 +23,7 @@ for name, lib in (("release", None), ("ref", os.path.abspath(sys.argv[1]))):
     env = dict(os.environ)
     if lib: env["IRIS_HIFIGAN_LIB"] = lib
     else: env.pop("IRIS_HIFIGAN_LIB", None)
-    p = subprocess.run([sys.executable, "-c", code, json.dumps(shapes)], env=env, capture_output=True, text=True)
+    p = subprocess.run([sys.executable, "-c", code, json.dumps(shapes), sys.argv[2] if len(sys.argv) > 2 else "f32"], env=env, capture_output=True, text=True)
     if p.returncode: print(p.stderr[-2000:]); sys.exit(1)
     res[name] = json.loads(p.stdout.strip().splitlines()[-1])
 bad = [k for k in res["release"] if res["release"][k] != res["ref"][k]]
