@@ -259,6 +259,9 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_f32_kernel(const PairLaunc
 #ifndef IRIS_PAIR_F32_DEFAULT
 #define IRIS_PAIR_F32_DEFAULT 1        // (A/B builds: -DIRIS_PAIR_F32_DEFAULT=0 keeps the separate launches)
 #endif
+#ifndef IRIS_PAIR_F32_SHORT_FACTOR
+#define IRIS_PAIR_F32_SHORT_FACTOR 2   // C = 64: 64-row tiles while 128-row jobs number fewer than this many per CU
+#endif
 struct PairTileF32 { int WT, WC, MT, MINB, M; };
 
 // Tile height (release builds, profiles/r02zd_*, r02zh_*): 128 rows -- four blocks per CU at C = 32, three at C = 64; 64 rows at
@@ -279,7 +282,7 @@ inline PairPlanF32 pair_f32_plan(const PairLaunchF32& a, int nz) {
     } else {
         pl.tile = PairTileF32{2, 2, 2, 3, 128};
         pl.tiles = tiles_of(128);
-        if (pl.tiles * nz * a.B < 2LL * n_cu) { pl.tile = PairTileF32{2, 2, 1, 4, 64}; pl.tiles = tiles_of(64); }
+        if (pl.tiles * nz * a.B < (long long)IRIS_PAIR_F32_SHORT_FACTOR * n_cu) { pl.tile = PairTileF32{2, 2, 1, 4, 64}; pl.tiles = tiles_of(64); }
     }
     return pl;
 }

@@ -1,7 +1,6 @@
 #!/bin/bash
-# round 3, call g: start-up stagger of the persistent fp32 MRF kernel's second residency generation; last upsampler at four blocks per CU
-set -o pipefail
-O=gpurun_out/r03g
-mkdir -p $O
-timeout -k 10 600 bash tools/ablate.sh "X=0" "IRIS_HIFIGAN_STAGGER=2" "IRIS_HIFIGAN_STAGGER=4" "IRIS_HIFIGAN_STAGGER=8" "IRIS_HIFIGAN_STAGGER=16" "IRIS_HIFIGAN_STAGGER=32" "X=0" "IRIS_HIFIGAN_CONV_MT=2" 2>&1 | grep -v amdgpu.ids | tee $O/ablate_stagger_1x1000.txt
-BENCH_ARGS="--batch 32 --frames 500" timeout -k 10 600 bash tools/ablate.sh "X=0" "IRIS_HIFIGAN_STAGGER=4" "IRIS_HIFIGAN_STAGGER=16" "X=0" 2>&1 | grep -v amdgpu.ids | tee $O/ablate_stagger_32x500.txt
+O=gpurun_out/r03g; mkdir -p $O
+for T in 100 282 700 1000; do for G in "" "--graph"; do
+  echo "T=$T $G $(timeout -k 10 120 python bench.py --frames $T --steps 100 --warmup 20 --no-cpu-baseline --no-extras $G 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["ms_per_step"],4))')" >> $O/graph.txt
+done; done
+cat $O/graph.txt
