@@ -796,7 +796,8 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     struct Entry { int key[8]; MrfPlan pl; bool used; };
     static thread_local Entry cache[16] = {};
     static thread_local int next = 0;
-    const int key[8] = {a.C_in, a.C_out, a.L_out, a.B, allow_zpar ? 1 : 0, plan_env, mrf_cu_count(), per_cu};
+    const bool has16 = a.p[0].wp16 && a.p[1].wp16 && a.p[2].wp16;      // (the small-problem kernel's packing: part of its applicability)
+    const int key[8] = {a.C_in, a.C_out, a.L_out, a.B, (allow_zpar ? 1 : 0) | (has16 ? 2 : 0) | (a.sum_y ? 4 : 0), plan_env, mrf_cu_count(), per_cu};
     for (const Entry& e : cache)
         if (e.used && memcmp(e.key, key, sizeof(key)) == 0) return e.pl;
     Entry& e = cache[next];

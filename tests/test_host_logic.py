@@ -340,6 +340,39 @@ def test_model_built_under_inference_mode(monkeypatch):
     assert m.engine() is not e1
 
 
+def test_launch_plan_of_the_wide_stages_follows_the_timing_model():
+    """mrf_plan (csrc/mrf_conv_mfma_f32.h) on the host: between whole rounds of tiles the wide fp32 stages run (tile, branch)
+    jobs in snake order (template argument `, 2>`), at exact rounds the tile-serial grid, on short inputs fixed per-branch
+    ranges or the small-problem kernel -- the choices the forced-plan sweeps of profiles/r03_plan_sweep/ found best -- and
+    every grid stays within two blocks per CU."""
+    cfg = GeneratorConfig()
+
+    def wide(frames, batch=1, cu=256):
+        plan = _native.describe_plan(cfg, batch, frames, _native.DTYPE_F32, cu_count=cu)
+        out = []
+        for l in plan["launches"]:
+            k = l["kernel"]
+            if k.startswith("mrf_conv_mfma_f32_kernel"):
+                args = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")
+                out.append({"mode": int(args[-1]), "sum": args[-2] == "true", "mt": int(args[2]), "grid": l["grid"][0]})
+            elif k.startswith("mrf_small"):
+                out.append({"mode": "small", "grid": l["grid"][0]})
+        return out
+
+    at700, at1000x4, at282, at100 = wide(700), wide(1000, 4), wide(282), wide(100)
+    assert all(l["mode"] == 2 and l["grid"] == 512 for l in at700[:12])                 # 350 / 1400 tiles on 512 slots: jobs
+    assert at700[0]["mt"] == 1 and at700[6]["mt"] == 2
+    assert all(l["mode"] == 0 and l["mt"] == 2 and l["grid"] in (500, 504, 512) for l in at1000x4[:12])   # whole rounds: tile-serial
+    assert at1000x4[5]["sum"] and at1000x4[11]["sum"]                                  # ... whose last step forms the mean itself
+    assert all(l["mode"] == 1 for l in at282[:12])                                      # fixed ranges
+    assert at100[0]["mode"] == "small" and at100[6]["mode"] == 2
+    for frames in (64, 100, 150, 282, 350, 500, 650, 700, 850, 1000, 1400, 2000):
+        for batch in (1, 3):
+            for l in wide(frames, batch):
+                assert 1 <= l["grid"] and (l["mode"] == "small" or l["grid"] <= 512), (frames, batch, l)
+    assert all(l["mode"] == "small" or l["grid"] <= 128 for l in wide(700, 1, cu=64))   # a smaller chip: its own slot count
+
+
 def test_describe_plan_on_the_host():
     """iris_hifigan_describe_plan: the forward's launch plan without a device -- the same code path as a forward
     (argument checks, workspace layout, mrf_plan / pair plans), every launch recorded instead of issued."""
