@@ -89,7 +89,6 @@ struct ConvLaunch {
     int n_ct;            // number of 32-wide C_out tiles in the packed weights
     unsigned* dyn_counter;  // MRF kernel: when set (zero at launch), blocks take their 2nd, 3rd, ... tile from this
                             // counter instead of a fixed stride (large batches: evens out slow and fast CUs)
-    int zdyn;               // MRF kernel, one-branch-per-block instantiation: (tile, branch) jobs drawn from dyn_counter instead of fixed ranges
     int stagger, stagger_mod;  // diagnostics only (IRIS_HIFIGAN_STAGGER): blocks of the second residency generation sleep first
     int zb1, zb2;           // MRF kernel, one-branch-per-block mode: blocks [0, zb1) serve branch 2 (k = 11),
                             // [zb1, zb2) branch 1 (k = 7), [zb2, gridDim.x) branch 0 (k = 3)

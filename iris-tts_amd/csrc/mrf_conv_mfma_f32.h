@@ -42,10 +42,10 @@ namespace iris {
 #define IRIS_MRF_FORCE_PLAN (-1)         // calibration builds (make relvariant EXTRA=-DIRIS_MRF_FORCE_PLAN=n): every launch in plan n
 #endif
 #ifndef IRIS_MRF_ZDYN_DEFAULT
-#define IRIS_MRF_ZDYN_DEFAULT 1          // (tile, branch) jobs from a counter where the estimate favours them (A/B builds: 0)
+#define IRIS_MRF_ZDYN_DEFAULT 1          // snake-ordered (tile, branch) jobs where the timing model favours them (A/B builds: 0)
 #endif
-#ifndef IRIS_MRF_ZDYN_OVERHEAD
-#define IRIS_MRF_ZDYN_OVERHEAD 1.02
+#ifndef IRIS_MRF_ZDYN_MIN_CHUNKS
+#define IRIS_MRF_ZDYN_MIN_CHUNKS 2       // ... on stages with at least this many C_in chunks (C >= 128: what the model was calibrated on)
 #endif
 #ifndef IRIS_ZPAR_ONE_PER_CU_DEFAULT
 #define IRIS_ZPAR_ONE_PER_CU_DEFAULT 1   // (A/B builds: 0 = one-branch-per-block mode always spreads over every block slot)
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     struct NextJob { bool valid; size_t batch_off; int i0; unsigned wvoff; const float* x; const f32x4* wp; int ks, dil, pad_left; };
 
     // One branch (problem p, KS taps) of tile `t`: all C_in chunks, then its epilogue.  get_next() is called once, at the
-    // start of the branch's LAST chunk (with jobs drawn from a counter the answer is only known by then), and says which
+    // start of the branch's LAST chunk, and says which
     // window and weights the last chunk prefetches.
     auto run_branch = [&](auto ks_tag, auto pi_tag, const Tile& t, auto get_next) {
         constexpr int KS = decltype(ks_tag)::value;
@@ -740,7 +740,7 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
     MrfPlan pl;
     pl.MT = 2; pl.zpar = false; pl.zdyn = false; pl.small = false; pl.zb1 = pl.zb2 = 0;
     const bool small_ok = allow_zpar && mrf_small_applicable(a, 3);
-    const bool zdyn_ok = allow_zpar && a.C_in >= 2 * t.CIC && n1 > 0;
+    const bool zdyn_ok = allow_zpar && a.C_in >= IRIS_MRF_ZDYN_MIN_CHUNKS * t.CIC && n1 > 0;
     if (plan_env >= 0 && plan_env <= 2) { pl.MT = plan_env == 0 ? 2 : 1; pl.zpar = plan_env == 2 && allow_zpar && zpar_units < 1e29; }
     else if (plan_env == 5 || plan_env == 6) { pl.MT = plan_env == 5 ? 1 : 2; pl.zpar = pl.zdyn = zdyn_ok; }
     else if (plan_env == 3) {
@@ -832,7 +832,6 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
     if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
     a.zb1 = pl.zb1; a.zb2 = pl.zb2;
-    a.zdyn = pl.zdyn ? 1 : 0;
     const long long n_tiles = pl.n_tiles, g = pl.grid;
     if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
