@@ -416,7 +416,14 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
     // to use either kind of counter skips the memset
     const bool pf_counters = h->tile_counters && (long long)B * T >= 100 &&
                              (int)h->stages.size() * h->cfg.num_dilations[0] <= kTileCounterWords / 2;
-    if ((dyn_tiles || pf_counters) && !h->host_only) HIP_TRY(hipMemsetAsync(h->tile_counters, 0, kTileCounterWords * sizeof(unsigned), stream));
+    // (zeroed where the first launch that reads them is about to be issued: a batch-1 forward of a few hundred frames has none)
+    bool counters_zeroed = false;
+    auto zero_counters = [&]() -> hipError_t {
+        if (counters_zeroed || h->host_only) return hipSuccess;
+        counters_zeroed = true;
+        return hipMemsetAsync(h->tile_counters, 0, kTileCounterWords * sizeof(unsigned), stream);
+    };
+    if (dyn_tiles) HIP_TRY(zero_counters());
 
     // ---- conv_pre (hifigan_pretrained.py:124) ----
     {
@@ -576,6 +583,7 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
                 TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 4.0 * n_el * nk * 5 + wbytes));
                 // (a zeroed counter word per persistent launch: the upper half of the per-forward counters)
                 unsigned* const ctr = (pf_counters && IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_PF_DYN", 1)) ? h->tile_counters + kTileCounterWords / 2 + ((int)i * nd + m) : nullptr;
+                if ((is_sum || pf) && ctr) HIP_TRY(zero_counters());
                 if (is_sum)  HIP_TRY(launch_pair_f32_pf(pa, nk, ws + w.y[0], ctr, stream));
                 else if (pf) HIP_TRY(launch_pair_f32_pf(pa, nk, nullptr, ctr, stream));
                 else         HIP_TRY(launch_pair_f32(pa, nk, stream));

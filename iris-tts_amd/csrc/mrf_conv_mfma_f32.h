@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         int tile = blockIdx.x;
         if (tile >= n_tiles) return;
         Tile t = make_tile(tile);
-        prologue(a.p[2].x, a.p[2].wp, a.p[2].ks, a.p[2].dil, a.p[2].pad_left, t);
+        prologue(a.p[2].x, a.p[2].wp, KC, a.p[2].dil, a.p[2].pad_left, t);        // (the host orders the branches: p[2] has KC taps)
         // dynamic mode: the next tile index comes from a global counter (first tile = blockIdx.x).  Thread 0 fetches
         // it at the start of a tile and leaves it in an LDS word behind the window; everybody reads it after the
         // barriers that end the first branch -- long before the last branch needs it for its prefetch.
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         Tile t = make_tile(tile);
         auto walk = [&](auto ks_tag, auto pi_tag) {
             constexpr int PI = decltype(pi_tag)::value;
-            prologue(a.p[PI].x, a.p[PI].wp, a.p[PI].ks, a.p[PI].dil, a.p[PI].pad_left, t);
+            prologue(a.p[PI].x, a.p[PI].wp, decltype(ks_tag)::value, a.p[PI].dil, a.p[PI].pad_left, t);
             for (;;) {
                 const int tile_next = tile + step;
                 const bool more = tile_next < n_tiles;
