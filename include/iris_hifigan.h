@@ -15,7 +15,11 @@
  *   - plain C, no C++/torch types; every pointer named *_dev is a HIP device pointer
  *     owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr()), *_host is host memory;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); forward is
- *     asynchronous on it and performs no allocation and no synchronisation;
+ *     asynchronous on it and performs no allocation and no synchronisation -- with ONE exception: the first forward of
+ *     IRIS_HIFIGAN_BF16 / IRIS_HIFIGAN_F32_SPLIT on a handle that was not prepared for that dtype
+ *     (iris_hifigan_prepare) builds the dtype's weight packing first (host repack, hipMalloc, synchronous upload).
+ *     Forwards of IRIS_HIFIGAN_F32 never do (create uploads everything fp32 needs).  Inside a stream capture that
+ *     lazy build is refused with IRIS_HIFIGAN_NOT_PREPARED instead of invalidating the capture;
  *   - every function returns an iris_hifigan_status; on failure the calling thread's
  *     message is available from iris_hifigan_last_error(); no exception crosses the ABI;
  *   - a handle may be used by one thread at a time, with ONE forward in flight: a handle owns per-forward
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define IRIS_HIFIGAN_ABI_VERSION 3
+#define IRIS_HIFIGAN_ABI_VERSION 4
 #define IRIS_HIFIGAN_MAX_STAGES 8    /* upsample stages            */
 #define IRIS_HIFIGAN_MAX_KERNELS 8   /* MRF branches per stage     */
 #define IRIS_HIFIGAN_MAX_DILATIONS 8 /* conv pairs per ResBlock    */
@@ -52,7 +56,10 @@ typedef enum iris_hifigan_status {
     IRIS_HIFIGAN_HIP_ERROR = 2,
     IRIS_HIFIGAN_OUT_OF_MEMORY = 3,
     IRIS_HIFIGAN_UNSUPPORTED = 4,
-    IRIS_HIFIGAN_WORKSPACE_TOO_SMALL = 5
+    IRIS_HIFIGAN_WORKSPACE_TOO_SMALL = 5,
+    IRIS_HIFIGAN_NOT_PREPARED = 6 /* a forward needs a weight packing that cannot be built now: the stream is being captured
+                                    (call iris_hifigan_prepare first), or the host weights were released before the dtype's
+                                    first use */
 } iris_hifigan_status;
 
 typedef enum iris_hifigan_dtype {
@@ -117,11 +124,17 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
                             uint64_t n_weights, iris_hifigan_handle** out);
 int32_t iris_hifigan_destroy(iris_hifigan_handle* h);
 
-/* create uploads the fp32 MFMA packing of the weights only.  The packings the other arithmetic needs (bf16 fragments for
- * IRIS_HIFIGAN_BF16, hi/mid bf16 planes for IRIS_HIFIGAN_F32_SPLIT, the 16x16 fragments of the short-input fp32 kernel for
- * IRIS_HIFIGAN_F32) are built on the first use of that dtype: by this call, or by the first forward of the dtype (which is
- * then synchronous and allocates once).  Call prepare before capturing forwards of a dtype into a hipGraph. */
+/* create uploads what IRIS_HIFIGAN_F32 needs (the 32x32 MFMA fragments and the 16x16 fragments of the short-input kernel;
+ * the repacking runs on up to 16 host threads).  The packings of the other arithmetic (bf16 fragments for IRIS_HIFIGAN_BF16,
+ * hi/mid bf16 planes for IRIS_HIFIGAN_F32_SPLIT) are built on the first use of that dtype: by this call, or by the first
+ * forward of the dtype (which is then synchronous and allocates once; refused with IRIS_HIFIGAN_NOT_PREPARED inside a stream
+ * capture).  A failed build (out of memory) is reported and retried by the next call; it does not disable the dtype.
+ * Call prepare before capturing forwards of a dtype into a hipGraph. */
 int32_t iris_hifigan_prepare(iris_hifigan_handle* h, int32_t dtype);
+/* Until both of those packings exist the handle keeps the reference-layout weights on the host (55.7 MB for V1, per handle)
+ * to build them from.  A caller that has prepared every dtype it will use drops that copy here; a later first use of
+ * another dtype then fails with IRIS_HIFIGAN_NOT_PREPARED. */
+int32_t iris_hifigan_release_host_weights(iris_hifigan_handle* h);
 
 /* Activation workspace needed by one forward of [B, in_channels, T].  Batch items are independent: a batch of more than
  * 65,536 mel frames in all runs as consecutive passes over sub-batches that share the workspace, so the figure is bounded
@@ -227,8 +240,8 @@ int32_t iris_hifigan_op_conv_post(const float* x0_dev, const float* x1_dev, cons
  * on fp32 channels-last tensors [B, L, C].  mean_dev != NULL makes it the last step of a stage: only
  * ((y_0 + y_1) + y_2) / 3 is stored, into mean_dev (y_dev is then unused).
  * plan: 0 = the library's own choice, 1 = persistent blocks with full-height tiles, 2 = with half-height tiles,
- * 3 = one branch per block, 4 = the small-problem kernel (16 x 16 jobs on v_mfma_f32_16x16x4_f32), 5 / 6 = (tile, branch)
- * jobs drawn from a counter at half / full tile height (C >= 128); all of them produce identical bits.  mean_dev is
+ * 3 = one branch per block, 4 = the small-problem kernel (16 x 16 jobs on v_mfma_f32_16x16x4_f32), 5 / 6 = snake-ordered
+ * (tile, branch) jobs at half / full tile height (C >= 128); all of them produce identical bits.  mean_dev is
  * available in plans 0-2.  Returns IRIS_HIFIGAN_UNSUPPORTED when the shape cannot take
  * the requested kernel. */
 int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* w_host, const float* const* bias_host,

@@ -392,9 +392,12 @@ inline size_t packed_conv1d_floats(int C_in, int C_out, int ks) {
 }
 
 // w: reference Conv1d layout [C_out][C_in][ks] (hifigan_pretrained.py:50-57).
-inline void pack_conv1d_weights(const float* w, int C_in, int C_out, int ks, float* out) {
+// Taps [kap0, kap1) only (kap1 < 0: all): the pieces are disjoint in `out`, so iris_hifigan_create packs them on several
+// host threads (host_parallel.h).
+inline void pack_conv1d_weights(const float* w, int C_in, int C_out, int ks, float* out, int kap0 = 0, int kap1 = -1) {
     const int Gp = packed_groups(C_in), n_ct = packed_cotiles(C_out);
-    for (int kap = 0; kap < ks; ++kap)
+    if (kap1 < 0 || kap1 > ks) kap1 = ks;
+    for (int kap = kap0; kap < kap1; ++kap)
         for (int g = 0; g < Gp; ++g)
             for (int ct = 0; ct < n_ct; ++ct)
                 for (int lane = 0; lane < 64; ++lane)
@@ -413,10 +416,11 @@ inline void pack_conv1d_weights(const float* w, int C_in, int C_out, int ks, flo
 //       = W[co = 16 ct16 + (lane & 15)][ci = 16 gp + {0, 2, 8, 10}[e] + {0, 4, 1, 5}[lane >> 4]][kap]     e = 0..3
 // i.e. the four A operands of the four MFMAs that cover 16 input channels, for K-quarter kq = lane >> 4.
 inline size_t packed16_conv1d_floats(int C_in, int C_out, int ks) { return (size_t)ks * C_in * C_out; }
-inline void pack_conv1d_weights16(const float* w, int C_in, int C_out, int ks, float* out) {
+inline void pack_conv1d_weights16(const float* w, int C_in, int C_out, int ks, float* out, int kap0 = 0, int kap1 = -1) {
     static const int kq_ch[4] = {0, 4, 1, 5}, e_ch[4] = {0, 2, 8, 10};
     const int ngp = C_in / 16, nct = C_out / 16;
-    for (int kap = 0; kap < ks; ++kap)
+    if (kap1 < 0 || kap1 > ks) kap1 = ks;
+    for (int kap = kap0; kap < kap1; ++kap)
         for (int gp = 0; gp < ngp; ++gp)
             for (int ct = 0; ct < nct; ++ct)
                 for (int lane = 0; lane < 64; ++lane)
@@ -435,11 +439,12 @@ inline int convt_taps(int k, int u) { return (k + u - 1) / u; }
 inline size_t packed_convt_phase_floats(int C_in, int C_out, int k, int u) {
     return packed_conv1d_floats(C_in, C_out, convt_taps(k, u));
 }
-inline void pack_convt_weights(const float* w, int C_in, int C_out, int k, int u, float* out) {
+inline void pack_convt_weights(const float* w, int C_in, int C_out, int k, int u, float* out, int ph0 = 0, int ph1 = -1) {
     const int taps = convt_taps(k, u);
     const int Gp = packed_groups(C_in), n_ct = packed_cotiles(C_out);
     const size_t phase_floats = packed_convt_phase_floats(C_in, C_out, k, u);
-    for (int ph = 0; ph < u; ++ph)
+    if (ph1 < 0 || ph1 > u) ph1 = u;
+    for (int ph = ph0; ph < ph1; ++ph)
         for (int kap = 0; kap < taps; ++kap) {
             const int kk = ph + (taps - 1 - kap) * u;  // index into the reference kernel axis
             for (int g = 0; g < Gp; ++g)

@@ -97,10 +97,11 @@ struct iris_hifigan_handle {
     float* blob_w16 = nullptr;   // device: ResBlock conv weights in v_mfma_f32_16x16x4_f32 fragment order (small-problem kernel), or null
     int hop = 1;
     int device = 0;
-    // Weight packings beyond the fp32 MFMA one are built on the first use of the dtype that needs them
-    // (iris_hifigan_prepare): the reference-layout weights are kept on the host until every packing exists.
+    // create uploads both fp32 packings; those of the other dtypes are built on first use (iris_hifigan_prepare, or the
+    // first forward of the dtype): the reference-layout weights are kept on the host until both exist or the caller
+    // releases them (iris_hifigan_release_host_weights).  built_* = the build succeeded, or the config cannot have it.
     std::vector<float> ref_weights;
-    bool tried_w16 = false, tried_bf16 = false, tried_s3 = false;
+    bool built_bf16 = false, built_s3 = false;
     bool host_only = false;     // iris_hifigan_describe_plan: no device memory behind the pointers, nothing is launched
     // profiling
     int profiling = 0;          // 0 off, 1 one record per launch, 2 the MRF launches of a stage share one record

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "generator_internal.h"
+#include "host_parallel.h"
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
 #include "mrf_small_f32.h"
@@ -167,6 +168,19 @@ WsLayout ws_layout(const iris_hifigan_handle* h, int B, int T) {
 
 void init_launch(ConvLaunch& a) { memset(&a, 0, sizeof(a)); a.out_stride = 1; }
 
+// second packing of the ResBlock conv weights for the small-problem kernel (mrf_small_f32.h): float offsets of each layer's
+// 16 x 16 fragments in blob_w16 (layers whose channel counts are not multiples of 16 keep -1: they never take that kernel)
+size_t assign_w16_offsets(iris_hifigan_handle* h) {
+    size_t off16 = 0;
+    for (auto& st : h->stages)
+        for (size_t j = 0; j < st.c1.size(); ++j)
+            for (int half = 0; half < 2; ++half)
+                for (auto& l : (half == 0 ? st.c1[j] : st.c2[j]))
+                    if ((l.C_in & 15) == 0 && (l.C_out & 15) == 0) { l.w16f_off = off16; off16 += packed16_conv1d_floats(l.C_in, l.C_out, l.k); }
+    return off16;
+}
+
+
 }  // namespace
 
 namespace iris {
@@ -216,35 +230,57 @@ int32_t iris_hifigan_create(const iris_hifigan_config* cfg, const float* weights
     if (n_weights != expect)
         return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "weight blob has %llu values, config needs %llu",
                     (unsigned long long)n_weights, (unsigned long long)expect);
+    // Repacking: the MFMA fragment order of the persistent kernels (32 x 32 tiles) and, for the ResBlock convs, the 16 x 16
+    // fragments of the short-input kernel (mrf_small_f32.h) -- two gathers over 13.9 M weights.  (layer, tap) pieces write
+    // disjoint ranges, so they run on a few host threads (host_parallel.h): the reference's caller loads a model to vocode ONE
+    // utterance (scripts/synthesize.py:197-198), so this is time that caller waits for.
     std::vector<float> host(h->blob_floats, 0.f);
-    const float* src = weights_host;
-    for_each_layer(h, [&](ConvLayer& l) {
-        float* dst = host.data() + l.w_off;
-        if (l.kind == 2) {
-            // [1][C][k] -> [k][C]
-            for (int c = 0; c < l.C_in; ++c)
-                for (int kap = 0; kap < l.k; ++kap) dst[(size_t)kap * l.C_in + c] = src[(size_t)c * l.k + kap];
-        } else if (l.kind == 1) {
-            pack_convt_weights(src, l.C_in, l.C_out, l.k, l.u, dst);
-        } else {
-            pack_conv1d_weights(src, l.C_in, l.C_out, l.k, dst);
-        }
-        src += l.ref_w_floats;
-        memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
-        src += l.C_out;
-    });
+    const size_t off16 = assign_w16_offsets(h);
+    std::vector<float> host16(off16);
+    std::vector<std::function<void()>> jobs;
+    {
+        const float* src = weights_host;
+        for_each_layer(h, [&](ConvLayer& l) {
+            float* dst = host.data() + l.w_off;
+            const ConvLayer* lp = &l;
+            if (l.kind == 2) {
+                jobs.push_back([=] {            // [1][C][k] -> [k][C]
+                    for (int c = 0; c < lp->C_in; ++c)
+                        for (int kap = 0; kap < lp->k; ++kap) dst[(size_t)kap * lp->C_in + c] = src[(size_t)c * lp->k + kap];
+                });
+            } else if (l.kind == 1) {
+                for (int ph = 0; ph < l.u; ++ph)
+                    jobs.push_back([=] { pack_convt_weights(src, lp->C_in, lp->C_out, lp->k, lp->u, dst, ph, ph + 1); });
+            } else {
+                for (int kap = 0; kap < l.k; ++kap)
+                    jobs.push_back([=] { pack_conv1d_weights(src, lp->C_in, lp->C_out, lp->k, dst, kap, kap + 1); });
+                if (l.w16f_off != (size_t)-1) {
+                    float* dst16 = host16.data() + l.w16f_off;
+                    for (int kap = 0; kap < l.k; ++kap)
+                        jobs.push_back([=] { pack_conv1d_weights16(src, lp->C_in, lp->C_out, lp->k, dst16, kap, kap + 1); });
+                }
+            }
+            src += l.ref_w_floats;
+            memcpy(host.data() + l.b_off, src, sizeof(float) * l.C_out);
+            src += l.C_out;
+        });
+    }
+    // the reference-layout weights stay on the host for the packings of the other dtypes (bf16 fragments, split-bf16 planes),
+    // which are built by iris_hifigan_prepare / the first forward of that dtype; iris_hifigan_release_host_weights drops them
+    jobs.push_back([=] { h->ref_weights.assign(weights_host, weights_host + n_weights); });
+    run_host_jobs(jobs);
     // the generator lives on the device that is current now; every later call runs under that device
     hipError_t e = hipGetDevice(&h->device);
     if (e == hipSuccess) e = hipMalloc(&h->blob, h->blob_floats * sizeof(float));
     if (e == hipSuccess)
         e = hipMemcpy(h->blob, host.data(), h->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && off16 > 0) e = hipMalloc(&h->blob_w16, off16 * sizeof(float));
+    if (e == hipSuccess && off16 > 0)
+        e = hipMemcpy(h->blob_w16, host16.data(), off16 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? IRIS_HIFIGAN_OUT_OF_MEMORY : IRIS_HIFIGAN_HIP_ERROR,
                     "weight upload failed: %s", hipGetErrorString(e));
     if (hipMalloc(&h->tile_counters, kTileCounterWords * sizeof(unsigned)) != hipSuccess) h->tile_counters = nullptr;   // optional
-    // the other packings (16 x 16 fragments of the small-problem kernel, bf16, split-bf16: ~150 MB together) are built by
-    // iris_hifigan_prepare / on the first forward of the dtype that needs them
-    h->ref_weights.assign(weights_host, weights_host + n_weights);
     owner.h = nullptr;
     *out = h;
     return IRIS_HIFIGAN_OK;
@@ -269,46 +305,27 @@ int32_t iris_hifigan_destroy(iris_hifigan_handle* h) {
 
 namespace {
 
-// second packing of the ResBlock conv weights for the small-problem kernel (mrf_small_f32.h): float offsets, then
-// (with weights) the packed fragments.  Optional: without it short inputs simply take the persistent kernel.
-size_t assign_w16_offsets(iris_hifigan_handle* h) {
-    size_t off16 = 0;
-    for (auto& st : h->stages)
-        for (size_t j = 0; j < st.c1.size(); ++j)
-            for (int half = 0; half < 2; ++half)
-                for (auto& l : (half == 0 ? st.c1[j] : st.c2[j]))
-                    if ((l.C_in & 15) == 0 && (l.C_out & 15) == 0) { l.w16f_off = off16; off16 += packed16_conv1d_floats(l.C_in, l.C_out, l.k); }
-    return off16;
-}
-
-void build_w16(iris_hifigan_handle* h, const float* weights_host) {
-    const size_t off16 = assign_w16_offsets(h);
-    if (off16 == 0) return;
-    std::vector<float> host16(off16);
-    const float* src16 = weights_host;
-    for_each_layer(h, [&](ConvLayer& l) {
-        if (l.w16f_off != (size_t)-1) pack_conv1d_weights16(src16, l.C_in, l.C_out, l.k, host16.data() + l.w16f_off);
-        src16 += l.ref_w_floats + l.C_out;
-    });
-    if (hipMalloc(&h->blob_w16, off16 * sizeof(float)) != hipSuccess ||
-        hipMemcpy(h->blob_w16, host16.data(), off16 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        if (h->blob_w16) (void)hipFree(h->blob_w16);
-        h->blob_w16 = nullptr;
+// Builds the weight packing `dtype` needs beyond what create uploaded (bf16 fragments / split-bf16 planes), once.
+// Synchronous (packs on the host, allocates, uploads).  A packing counts as built only when its build SUCCEEDED or the
+// configuration genuinely cannot have it (then the forward of that dtype reports UNSUPPORTED): a transient failure -- out
+// of memory -- is reported and retried by the next call.  `stream` non-null-checked: inside a stream capture nothing may
+// allocate or synchronise, so a forward that still needs a packing there is refused with NOT_PREPARED.
+int ensure_prepared(iris_hifigan_handle* h, int32_t dtype, hipStream_t stream, bool from_forward) {
+    const bool want_bf16 = dtype == IRIS_HIFIGAN_BF16 && !h->built_bf16;
+    const bool want_s3 = dtype == IRIS_HIFIGAN_F32_SPLIT && !h->built_s3;
+    if (!want_bf16 && !want_s3) return IRIS_HIFIGAN_OK;
+    if (from_forward) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(IRIS_HIFIGAN_NOT_PREPARED, "the weight packing of dtype %d is not built yet and the stream is being captured: "
+                        "call iris_hifigan_prepare(h, %d) before capturing forwards of this dtype", dtype, dtype);
     }
-}
-
-// Builds the weight packings `dtype` needs, once.  Synchronous (allocates and uploads): the first forward of a dtype
-// does it itself; a caller that captures forwards into a hipGraph calls iris_hifigan_prepare beforehand.
-int ensure_prepared(iris_hifigan_handle* h, int32_t dtype) {
-    const bool want_w16 = (dtype == IRIS_HIFIGAN_F32 || dtype == IRIS_HIFIGAN_F32_SPLIT) && !h->tried_w16;
-    const bool want_bf16 = dtype == IRIS_HIFIGAN_BF16 && !h->tried_bf16;
-    const bool want_s3 = dtype == IRIS_HIFIGAN_F32_SPLIT && !h->tried_s3;
-    if (!want_w16 && !want_bf16 && !want_s3) return IRIS_HIFIGAN_OK;
-    if (h->ref_weights.empty()) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "generator holds no weights to pack");
-    if (want_w16)  { h->tried_w16 = true; build_w16(h, h->ref_weights.data()); }
-    if (want_bf16) { h->tried_bf16 = true; TRY(bf16_build_blob(h, h->ref_weights.data())); }
-    if (want_s3)   { h->tried_s3 = true; TRY(f32s_build_blob(h, h->ref_weights.data())); }
-    if (h->tried_w16 && h->tried_bf16 && h->tried_s3) std::vector<float>().swap(h->ref_weights);   // every packing exists
+    if (h->ref_weights.empty())
+        return fail(IRIS_HIFIGAN_NOT_PREPARED, "the host copy of the weights was released (iris_hifigan_release_host_weights) before "
+                    "dtype %d was prepared", dtype);
+    if (want_bf16) { TRY(bf16_build_blob(h, h->ref_weights.data())); h->built_bf16 = true; }
+    if (want_s3)   { TRY(f32s_build_blob(h, h->ref_weights.data())); h->built_s3 = true; }
+    if (h->built_bf16 && h->built_s3) std::vector<float>().swap(h->ref_weights);   // every packing exists
     return IRIS_HIFIGAN_OK;
 }
 
@@ -323,8 +340,14 @@ int32_t iris_hifigan_prepare(iris_hifigan_handle* h, int32_t dtype) {
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "dtype %d not supported", dtype);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
-    return ensure_prepared(h, dtype);
+    return ensure_prepared(h, dtype, nullptr, false);
     IRIS_ABI_END
+}
+
+int32_t iris_hifigan_release_host_weights(iris_hifigan_handle* h) {
+    if (!h) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL handle");
+    std::vector<float>().swap(h->ref_weights);
+    return IRIS_HIFIGAN_OK;
 }
 
 int32_t iris_hifigan_hop_length(const iris_hifigan_handle* h, int32_t* hop) {
@@ -680,7 +703,7 @@ int32_t iris_hifigan_forward(iris_hifigan_handle* h, const void* mel_dev, int32_
     if (!wav_dev) return fail(IRIS_HIFIGAN_INVALID_ARGUMENT, "NULL device pointer");
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
-    TRY(ensure_prepared(h, dtype));
+    TRY(ensure_prepared(h, dtype, (hipStream_t)stream_, true));
     if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     const ForwardStop none{-1, -1};
@@ -710,7 +733,7 @@ int32_t iris_hifigan_forward_until(iris_hifigan_handle* h, const void* mel_dev, 
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "forward_until takes shapes that run in one pass (B * T <= %d frames)", kPassFrames);
     DeviceGuard guard(h->device);
     if (guard.err != hipSuccess) return fail(IRIS_HIFIGAN_HIP_ERROR, "cannot select device %d: %s", h->device, hipGetErrorString(guard.err));
-    TRY(ensure_prepared(h, dtype));
+    TRY(ensure_prepared(h, dtype, (hipStream_t)stream_, true));
     if (dtype == IRIS_HIFIGAN_F32_SPLIT && !h->blob_s3)
         return fail(IRIS_HIFIGAN_UNSUPPORTED, "split-product mode needs ResBlock channel counts that are multiples of 32");
     const ForwardStop stop{stop_stage, stop_step};
@@ -735,9 +758,8 @@ int32_t iris_hifigan_describe_plan(const iris_hifigan_config* cfg, int32_t B, in
     h.blob = reinterpret_cast<float*>((uintptr_t)0x10000000);
     h.tile_counters = reinterpret_cast<unsigned*>((uintptr_t)0x08000000);
     if (assign_w16_offsets(&h) > 0) h.blob_w16 = reinterpret_cast<float*>((uintptr_t)0x18000000);
-    h.tried_w16 = true;
-    TRY(bf16_build_blob(&h, nullptr)); h.tried_bf16 = true;
-    TRY(f32s_build_blob(&h, nullptr)); h.tried_s3 = true;
+    TRY(bf16_build_blob(&h, nullptr)); h.built_bf16 = true;
+    TRY(f32s_build_blob(&h, nullptr)); h.built_s3 = true;
     void* const mel = reinterpret_cast<void*>((uintptr_t)0x40000000);
     void* const wav = reinterpret_cast<void*>((uintptr_t)0x50000000);
     void* const ws = reinterpret_cast<void*>((uintptr_t)0x100000000ull);

@@ -5,6 +5,7 @@
 //   grouped MRF launches } -> conv_post + tanh (fp32 waveform out).
 // The MRF mean is formed by the consumer of a stage while it stages its input (SURVEY.md 8d accounting L).
 #include "generator_internal.h"
+#include "host_parallel.h"
 #include "conv_mfma_bf16.h"
 #include "mrf_pair_bf16.h"
 #ifdef IRIS_MRF_DIAG
@@ -65,12 +66,15 @@ int bf16_build_blob(iris_hifigan_handle* h, const float* weights_host) {
     if (h->host_only) { h->blob16 = reinterpret_cast<uint16_t*>((uintptr_t)0x20000000); return IRIS_HIFIGAN_OK; }   // offsets only
     std::vector<uint16_t> host(off, 0);
     const float* src = weights_host;
+    std::vector<std::function<void()>> jobs;          // one per layer, on a few host threads (host_parallel.h)
     for_each_layer(h, [&](ConvLayer& l) {
         uint16_t* dst = host.data() + l.w16_off;
-        if (l.kind == 1)      pack_convt_bf16(src, l.C_in, l.C_out, l.k, l.u, dst);
-        else if (l.kind == 0) pack_conv1d_bf16(src, l.C_in, l.C_out, l.k, dst);
+        const ConvLayer* lp = &l;
+        if (l.kind == 1)      jobs.push_back([=] { pack_convt_bf16(src, lp->C_in, lp->C_out, lp->k, lp->u, dst); });
+        else if (l.kind == 0) jobs.push_back([=] { pack_conv1d_bf16(src, lp->C_in, lp->C_out, lp->k, dst); });
         src += l.ref_w_floats + l.C_out;
     });
+    run_host_jobs(jobs);
     hipError_t e = hipMalloc(&h->blob16, off * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(h->blob16, host.data(), off * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -101,11 +105,15 @@ int f32s_build_blob(iris_hifigan_handle* h, const float* weights_host) {
     if (h->host_only) { h->blob_s3 = reinterpret_cast<uint16_t*>((uintptr_t)0x30000000); return IRIS_HIFIGAN_OK; }   // offsets only
     std::vector<uint16_t> host(off, 0);
     const float* src = weights_host;
+    std::vector<std::function<void()>> jobs;
     for_each_layer(h, [&](ConvLayer& l) {
-        if (l.kind == 0 && &l != &h->pre) s3::pack_conv1d_split(src, l.C_in, l.C_out, l.k, host.data() + l.ws3_off);
-        if (l.kind == 1) s3::pack_convt_split(src, l.C_in, l.C_out, l.k, l.u, host.data() + l.ws3_off);
+        uint16_t* dst = host.data() + l.ws3_off;
+        const ConvLayer* lp = &l;
+        if (l.kind == 0 && &l != &h->pre) jobs.push_back([=] { s3::pack_conv1d_split(src, lp->C_in, lp->C_out, lp->k, dst); });
+        if (l.kind == 1) jobs.push_back([=] { s3::pack_convt_split(src, lp->C_in, lp->C_out, lp->k, lp->u, dst); });
         src += l.ref_w_floats + l.C_out;
     });
+    run_host_jobs(jobs);
     hipError_t e = hipMalloc(&h->blob_s3, off * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(h->blob_s3, host.data(), off * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {

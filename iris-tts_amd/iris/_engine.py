@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from typing import List, Mapping, Optional
 
 import numpy as np
@@ -16,6 +17,11 @@ import torch
 
 from . import _native
 from ._weights import GeneratorConfig, expected_weight_count, weight_blob
+
+# wall-clock of the most recent cold start, filled in as its steps run (bench.py's `load` record): the checkpoint loader
+# adds torch_load_ms / model_construct_ms / load_state_dict_ms, the engine constructor fold_ms (weight-norm fold into the
+# blob) and create_ms (iris_hifigan_create: host repack into fragment order + upload)
+LAST_LOAD_TIMINGS: dict = {}
 
 KIND_NAMES = {0: "conv_pre", 1: "upsample", 2: "mrf_resblock_conv", 3: "conv_post"}
 DTYPES = {"f32": _native.DTYPE_F32, "bf16": _native.DTYPE_BF16, "f32s": _native.DTYPE_F32_SPLIT}
@@ -45,8 +51,13 @@ class GeneratorEngine:
     calls select the engine's device themselves (``include/iris_hifigan.h``), so an engine may live on a GPU
     that is not the caller's current device."""
 
+    # forward() replays a captured hipGraph instead of issuing 24-30 launches when batch * frames is at most this many mel
+    # frames (the forward is then launch-/latency-bound: 0.84 -> 0.81 ms at 100 frames, 1.5 % at 282, nothing from ~700 on)
+    GRAPH_MAX_FRAMES = 384
+
     def __init__(self, cfg: GeneratorConfig, state_dict: Mapping[str, object],
-                 device: Optional[torch.device] = None, dtype: Optional[str] = None):
+                 device: Optional[torch.device] = None, dtype: Optional[str] = None,
+                 graph_max_frames: Optional[int] = None):
         # default arithmetic of forward(): "f32" unless the caller or IRIS_VOCODER_DTYPE says "bf16" (the drop-in
         # wrappers construct engines without a dtype, so the environment variable switches them too)
         self.default_dtype = dtype or os.environ.get("IRIS_VOCODER_DTYPE", "f32")
@@ -56,20 +67,27 @@ class GeneratorEngine:
         self.device = device if device is not None else require_gpu()
         if self.device.type != "cuda":
             raise RuntimeError(f"GeneratorEngine needs a HIP device, got {self.device}")
+        t0 = time.perf_counter()
         blob = weight_blob(cfg, state_dict)
         assert blob.size == expected_weight_count(cfg)
+        t1 = time.perf_counter()
         self._handle = ctypes.c_void_p()
         ccfg = _native.make_config(cfg)
         with torch.cuda.device(self.device):
             _native.check("iris_hifigan_create", self.lib.iris_hifigan_create(
                 ctypes.byref(ccfg), blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                 ctypes.c_uint64(blob.size), ctypes.byref(self._handle)))
+        LAST_LOAD_TIMINGS.update({"fold_ms": 1e3 * (t1 - t0), "create_ms": 1e3 * (time.perf_counter() - t1)})
         hop = ctypes.c_int32()
         _native.check("iris_hifigan_hop_length", self.lib.iris_hifigan_hop_length(self._handle, ctypes.byref(hop)))
         self.hop_length = int(hop.value)
         self._workspace: Optional[torch.Tensor] = None
         self._graphs: dict = {}
         self._profiling = 0
+        # 0 = always eager; the environment variable switches the drop-in wrappers (which construct engines themselves)
+        if graph_max_frames is None:
+            graph_max_frames = int(os.environ.get("IRIS_VOCODER_GRAPH_FRAMES", self.GRAPH_MAX_FRAMES))
+        self.graph_max_frames = max(0, int(graph_max_frames))
 
     # -- lifetime ----------------------------------------------------------------------------
     def close(self) -> None:
@@ -125,6 +143,13 @@ class GeneratorEngine:
             raise ValueError("out must be a contiguous fp32 tensor [B, hop*T]")
         if batch == 0 or frames == 0:
             return out
+        if (batch * frames <= self.graph_max_frames and not self._profiling
+                and not torch.cuda.is_current_stream_capturing()):
+            # short inputs: one graph launch instead of 24-30 kernel launches.  The graph owns static buffers; the result is
+            # copied into `out` (a fresh tensor unless the caller gave one), so nothing the caller holds is overwritten by
+            # the next call.  Profiling (per-launch events) and captures by the caller take the eager path below.
+            out.copy_(self._replay(mel, dtype))
+            return out
         nbytes = self.workspace_bytes(batch, frames, dtype)
         ws = self._get_workspace(nbytes)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -141,8 +166,9 @@ class GeneratorEngine:
         """Same result as ``forward`` but the launches of one forward are captured once per
         (batch, frames) into a hipGraph and replayed: the host issues one graph launch instead of 24-30
         kernel launches, and the inter-kernel gaps shrink to the graph's own.  ``iris_hifigan_forward`` is
-        capture-safe by construction (no allocation, no synchronisation, caller's stream).  The returned
-        tensor is the graph's static output buffer: it is overwritten by the next replay of the same shape.
+        capture-safe by construction (no allocation, no synchronisation, caller's stream; the packing of a dtype other
+        than fp32 is built BEFORE the capture).  The returned tensor is the graph's static output buffer: it is
+        overwritten by the next replay of the same shape (``forward`` on a short input copies it out instead).
         Per-launch profiling records are not produced in this mode."""
         dtype = dtype or self.default_dtype
         if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
@@ -150,17 +176,36 @@ class GeneratorEngine:
         batch, _, frames = mel.shape
         if batch == 0 or frames == 0:
             return self.forward(mel, dtype=dtype)
+        return self._replay(mel, dtype)
+
+    def _replay(self, mel: torch.Tensor, dtype: str) -> torch.Tensor:
+        batch, _, frames = mel.shape
         key = (batch, frames, dtype)
         entry = self._graphs.get(key)
+        if entry is not None and (self._workspace is None or self._workspace.data_ptr() != entry[3]):
+            # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
+            del self._graphs[key]
+            entry = None
         if entry is None:
-            static_in = torch.empty((batch, self.cfg.in_channels, frames), dtype=torch.float32, device=self.device)
-            static_out = torch.empty((batch, frames * self.hop_length), dtype=torch.float32, device=self.device)
-            self._get_workspace(self.workspace_bytes(batch, frames, dtype))     # allocate before capture
-            ws_ptr = self._workspace.data_ptr()
-            static_in.copy_(mel)
-            was_profiling = self._profiling
-            if was_profiling:                    # no event records inside a capture; the records collected so far are kept
-                _native.check("iris_hifigan_pause_profiling", self.lib.iris_hifigan_pause_profiling(self._handle, 1))
+            entry = self._capture(mel, key)
+        graph, static_in, static_out, _ = entry
+        static_in.copy_(mel.to(device=self.device, dtype=torch.float32))
+        graph.replay()
+        return static_out
+
+    def _capture(self, mel: torch.Tensor, key) -> tuple:
+        batch, frames, dtype = key
+        static_in = torch.empty((batch, self.cfg.in_channels, frames), dtype=torch.float32, device=self.device)
+        static_out = torch.empty((batch, frames * self.hop_length), dtype=torch.float32, device=self.device)
+        self.prepare(dtype)                                                  # nothing may be built inside the capture
+        self._get_workspace(self.workspace_bytes(batch, frames, dtype))     # allocate before capture
+        ws_ptr = self._workspace.data_ptr()
+        static_in.copy_(mel)
+        was_profiling = self._profiling
+        limit, self.graph_max_frames = self.graph_max_frames, 0             # the forwards below are the eager ones
+        if was_profiling:                    # no event records inside a capture; the records collected so far are kept
+            _native.check("iris_hifigan_pause_profiling", self.lib.iris_hifigan_pause_profiling(self._handle, 1))
+        try:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                                # warm-up outside capture
@@ -169,24 +214,27 @@ class GeneratorEngine:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self.forward(static_in, out=static_out, dtype=dtype)
-            entry = (graph, static_in, static_out, ws_ptr)
-            self._graphs[key] = entry
+        finally:
+            self.graph_max_frames = limit
             if was_profiling:
                 _native.check("iris_hifigan_pause_profiling", self.lib.iris_hifigan_pause_profiling(self._handle, 0))
-        graph, static_in, static_out, ws_ptr = entry
-        if self._workspace is None or self._workspace.data_ptr() != ws_ptr:
-            # the workspace was re-allocated (a larger shape came by): the captured pointers are stale
-            del self._graphs[key]
-            return self.forward_graph(mel, dtype=dtype)
-        static_in.copy_(mel.to(device=self.device, dtype=torch.float32))
-        graph.replay()
-        return static_out
+        entry = (graph, static_in, static_out, ws_ptr)
+        if len(self._graphs) >= 32:                                      # (bounded: a caller with many distinct short shapes)
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = entry
+        return entry
 
     def prepare(self, dtype: Optional[str] = None) -> None:
-        """Builds the weight packing ``dtype`` needs now (otherwise the first forward of the dtype does, synchronously)."""
+        """Builds the weight packing ``dtype`` needs now (otherwise the first forward of the dtype does, synchronously).
+        fp32 needs nothing beyond what the constructor uploaded."""
         code = _dtype_code(dtype or self.default_dtype)
         with torch.cuda.device(self.device):
             _native.check("iris_hifigan_prepare", self.lib.iris_hifigan_prepare(self._handle, code))
+
+    def release_host_weights(self) -> None:
+        """Drops the native handle's host copy of the reference-layout weights (55.7 MB for V1), which it keeps to build
+        the bf16 / split-product packings on first use.  After this, a dtype that was not prepared cannot be used."""
+        _native.check("iris_hifigan_release_host_weights", self.lib.iris_hifigan_release_host_weights(self._handle))
 
     # -- profiling (bench.py roofline leg) -----------------------------------------------------
     def set_profiling(self, enabled) -> None:

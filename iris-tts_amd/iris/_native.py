@@ -14,12 +14,15 @@ from typing import Optional
 MAX_STAGES = 8
 MAX_KERNELS = 8
 MAX_DILATIONS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_PLAN_LAUNCHES = 96
 
 DTYPE_F32 = 0
 DTYPE_BF16 = 1
 DTYPE_F32_SPLIT = 2
+
+STATUS_WORKSPACE_TOO_SMALL = 5
+STATUS_NOT_PREPARED = 6
 
 LIB_NAME = "libiris_hifigan.so"
 CSRC_DIR = Path(__file__).resolve().parent.parent / "csrc"
@@ -120,6 +123,7 @@ SYMBOLS = {
     "iris_hifigan_create": (_i32, [_c.POINTER(Config), _fp, _u64, _c.POINTER(_vp)]),
     "iris_hifigan_destroy": (_i32, [_vp]),
     "iris_hifigan_prepare": (_i32, [_vp, _i32]),
+    "iris_hifigan_release_host_weights": (_i32, [_vp]),
     "iris_hifigan_pause_profiling": (_i32, [_vp, _i32]),
     "iris_hifigan_describe_plan": (_i32, [_c.POINTER(Config), _i32, _i32, _i32, _i32, _c.POINTER(Plan)]),
     "iris_hifigan_workspace_bytes": (_i32, [_vp, _i32, _i32, _i32, _c.POINTER(_u64)]),

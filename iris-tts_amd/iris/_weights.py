@@ -15,7 +15,7 @@ Reference facts restated here (all read from the reference as text):
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, Iterable, Iterator, List, Mapping, Sequence, Tuple
+from typing import Dict, Iterable, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -121,14 +121,17 @@ def state_dict_keys(cfg: GeneratorConfig) -> List[str]:
 # --------------------------------------------------------------------------------------------
 # weight-norm folding
 # --------------------------------------------------------------------------------------------
-def fold_weight_norm(weight_g: np.ndarray, weight_v: np.ndarray) -> np.ndarray:
+def fold_weight_norm(weight_g: np.ndarray, weight_v: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
     """w = v * (g / ||v||_2), the norm taken over all dims except dim 0, in fp32 like
-    ``torch._weight_norm`` (used by nn.utils.weight_norm at hifigan_pretrained.py:49,55,92,100,119)."""
+    ``torch._weight_norm`` (used by nn.utils.weight_norm at hifigan_pretrained.py:49,55,92,100,119).
+    ``out``: an fp32 array of v's shape to write into (``weight_blob`` folds straight into the blob)."""
     v = np.asarray(weight_v, dtype=np.float32)
     g = np.asarray(weight_g, dtype=np.float32).reshape(v.shape[0], *([1] * (v.ndim - 1)))
     norm = np.sqrt(np.sum(np.square(v, dtype=np.float32), axis=tuple(range(1, v.ndim)), keepdims=True,
                           dtype=np.float32))
-    return (v * (g / norm)).astype(np.float32)
+    if out is None:
+        out = np.empty(v.shape, dtype=np.float32)
+    return np.multiply(v, g / norm, out=out)
 
 
 def _to_numpy(t) -> np.ndarray:
@@ -139,33 +142,54 @@ def _to_numpy(t) -> np.ndarray:
     return np.asarray(t)
 
 
-def folded_layers(cfg: GeneratorConfig, state_dict: Mapping[str, object]) -> List[Tuple[LayerSpec, np.ndarray, np.ndarray]]:
-    """[(spec, weight fp32 in reference layout, bias fp32)] for every layer.
-    Accepts weight-normed entries (``weight_g``/``weight_v``) or plain ``weight``."""
-    out = []
-    for s in layer_specs(cfg):
-        if f"{s.name}.weight_v" in state_dict:
-            w = fold_weight_norm(_to_numpy(state_dict[f"{s.name}.weight_g"]), _to_numpy(state_dict[f"{s.name}.weight_v"]))
-        elif f"{s.name}.weight" in state_dict:
-            w = np.asarray(_to_numpy(state_dict[f"{s.name}.weight"]), dtype=np.float32)
-        else:
-            raise KeyError(f"state dict has neither {s.name}.weight_v nor {s.name}.weight")
+def _layer_tensors(s: LayerSpec, state_dict: Mapping[str, object], w_out: Optional[np.ndarray] = None,
+                   b_out: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Folded weight (reference layout, fp32) and bias of one layer, validated; written into ``w_out`` / ``b_out`` when
+    given.  Accepts weight-normed entries (``weight_g``/``weight_v``) or plain ``weight``."""
+    if f"{s.name}.weight_v" in state_dict:
+        v = _to_numpy(state_dict[f"{s.name}.weight_v"])
+        if tuple(v.shape) != s.weight_shape:
+            raise ValueError(f"{s.name}: weight shape {tuple(v.shape)} != expected {s.weight_shape}")
+        w = fold_weight_norm(_to_numpy(state_dict[f"{s.name}.weight_g"]), v, out=w_out)
+    elif f"{s.name}.weight" in state_dict:
+        w = np.asarray(_to_numpy(state_dict[f"{s.name}.weight"]), dtype=np.float32)
         if tuple(w.shape) != s.weight_shape:
             raise ValueError(f"{s.name}: weight shape {tuple(w.shape)} != expected {s.weight_shape}")
-        b = np.asarray(_to_numpy(state_dict[f"{s.name}.bias"]), dtype=np.float32)
-        if b.shape != (s.c_out,):
-            raise ValueError(f"{s.name}: bias shape {b.shape} != ({s.c_out},)")
+        if w_out is not None:
+            w_out[...] = w
+            w = w_out
+    else:
+        raise KeyError(f"state dict has neither {s.name}.weight_v nor {s.name}.weight")
+    b = np.asarray(_to_numpy(state_dict[f"{s.name}.bias"]), dtype=np.float32)
+    if b.shape != (s.c_out,):
+        raise ValueError(f"{s.name}: bias shape {b.shape} != ({s.c_out},)")
+    if b_out is not None:
+        b_out[...] = b
+        b = b_out
+    return w, b
+
+
+def folded_layers(cfg: GeneratorConfig, state_dict: Mapping[str, object]) -> List[Tuple[LayerSpec, np.ndarray, np.ndarray]]:
+    """[(spec, weight fp32 in reference layout, bias fp32)] for every layer."""
+    out = []
+    for s in layer_specs(cfg):
+        w, b = _layer_tensors(s, state_dict)
         out.append((s, np.ascontiguousarray(w), np.ascontiguousarray(b)))
     return out
 
 
 def weight_blob(cfg: GeneratorConfig, state_dict: Mapping[str, object]) -> np.ndarray:
-    """Flat fp32 blob for ``iris_hifigan_create``: weight then bias of every layer, reference layouts."""
-    parts = []
-    for _, w, b in folded_layers(cfg, state_dict):
-        parts.append(w.ravel())
-        parts.append(b.ravel())
-    return np.ascontiguousarray(np.concatenate(parts).astype(np.float32))
+    """Flat fp32 blob for ``iris_hifigan_create``: weight then bias of every layer, reference layouts.  Every layer is
+    folded straight into its place in the blob (one pass over the 13.9 M values: this is part of the cold start of the
+    reference's load-then-vocode-once caller, scripts/synthesize.py:197-198)."""
+    blob = np.empty(expected_weight_count(cfg), dtype=np.float32)
+    off = 0
+    for s in layer_specs(cfg):
+        n = int(np.prod(s.weight_shape))
+        _layer_tensors(s, state_dict, blob[off:off + n].reshape(s.weight_shape), blob[off + n:off + n + s.c_out])
+        off += n + s.c_out
+    assert off == blob.size
+    return blob
 
 
 def expected_weight_count(cfg: GeneratorConfig) -> int:

@@ -23,6 +23,7 @@ objects, hifigan_pretrained.py:165) and key mismatches are logged instead of sil
 from __future__ import annotations
 
 import logging
+import time
 from pathlib import Path
 from typing import List, Optional, Sequence, Union
 
@@ -30,7 +31,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ._engine import GeneratorEngine, require_gpu
+from ._engine import LAST_LOAD_TIMINGS, GeneratorEngine, require_gpu
 from ._weights import GeneratorConfig, layer_specs, extract_state_dict
 
 logger = logging.getLogger(__name__)
@@ -42,15 +43,26 @@ class _WeightNormedConv(nn.Module):
     """Parameter holder with the reference's weight-norm parametrisation
     (``weight_g``, ``weight_v``, ``bias``); the arithmetic lives in the HIP library."""
 
-    def __init__(self, weight_shape: Sequence[int], c_out: int):
+    def __init__(self, weight_shape: Sequence[int], c_out: int, init: bool = True):
         super().__init__()
-        fan_in = weight_shape[1] * weight_shape[2]
-        bound = 1.0 / float(np.sqrt(fan_in))
-        v = torch.empty(*weight_shape, dtype=torch.float32).uniform_(-bound, bound)
-        self.bias = nn.Parameter(torch.empty(c_out, dtype=torch.float32).uniform_(-bound, bound), requires_grad=False)
-        # weight_norm initialises g to ||v|| so that the effective weight equals v
-        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).reshape(-1, 1, 1).clone(), requires_grad=False)
-        self.weight_v = nn.Parameter(v, requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(c_out, dtype=torch.float32), requires_grad=False)
+        self.weight_g = nn.Parameter(torch.empty(weight_shape[0], 1, 1, dtype=torch.float32), requires_grad=False)
+        self.weight_v = nn.Parameter(torch.empty(*weight_shape, dtype=torch.float32), requires_grad=False)
+        self.initialised = False
+        if init:
+            self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        """torch's default conv init (U(+-1/sqrt(fan_in)) for weight and bias); weight_norm sets g = ||v|| so that the
+        effective weight equals v.  A checkpoint loader that is about to overwrite the parameters defers this (13.9 M
+        random numbers are a tenth of a second of its cold start) and runs it only for layers the checkpoint lacks."""
+        shape = self.weight_v.shape
+        bound = 1.0 / float(np.sqrt(shape[1] * shape[2]))
+        with torch.no_grad():
+            self.weight_v.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+            self.weight_g.copy_(self.weight_v.flatten(1).norm(dim=1).reshape(-1, 1, 1))
+        self.initialised = True
 
     @property
     def weight(self) -> torch.Tensor:
@@ -64,12 +76,12 @@ class ResBlock(nn.Module):
     -- reference hifigan_pretrained.py:38-71.  It cannot be called on its own: the fused MRF
     kernels advance all branches of a stage together."""
 
-    def __init__(self, channels: int, kernel_size: int = 3, dilations: Sequence[int] = (1, 3, 5)):
+    def __init__(self, channels: int, kernel_size: int = 3, dilations: Sequence[int] = (1, 3, 5), _init_weights: bool = True):
         super().__init__()
         self.channels, self.kernel_size, self.dilations = channels, kernel_size, tuple(dilations)
         shape = (channels, channels, kernel_size)
-        self.convs1 = nn.ModuleList(_WeightNormedConv(shape, channels) for _ in self.dilations)
-        self.convs2 = nn.ModuleList(_WeightNormedConv(shape, channels) for _ in self.dilations)
+        self.convs1 = nn.ModuleList(_WeightNormedConv(shape, channels, _init_weights) for _ in self.dilations)
+        self.convs2 = nn.ModuleList(_WeightNormedConv(shape, channels, _init_weights) for _ in self.dilations)
 
     def forward(self, x):  # pragma: no cover - deliberate
         raise RuntimeError("ResBlock is a parameter container in the MI355X build; call HiFiGANModel")
@@ -87,7 +99,10 @@ class HiFiGANModel(nn.Module):
         upsample_initial_channel: int = 512,
         resblock_kernel_sizes: Sequence[int] = (3, 7, 11),
         resblock_dilation_sizes: Sequence[Sequence[int]] = ((1, 3, 5), (1, 3, 5), (1, 3, 5)),
+        _init_weights: bool = True,
     ):
+        """``_init_weights=False`` (not in the reference; used by the checkpoint loader below): parameters are allocated but
+        not drawn; ``finish_init`` then draws only the layers a checkpoint did not provide."""
         super().__init__()
         self.config = GeneratorConfig(
             in_channels=in_channels,
@@ -101,16 +116,16 @@ class HiFiGANModel(nn.Module):
         self.num_kernels = cfg.num_kernels
         self.num_upsamples = cfg.num_upsamples
         specs = {s.name: s for s in layer_specs(cfg)}
-        self.conv_pre = _WeightNormedConv(specs["conv_pre"].weight_shape, specs["conv_pre"].c_out)
+        self.conv_pre = _WeightNormedConv(specs["conv_pre"].weight_shape, specs["conv_pre"].c_out, _init_weights)
         self.ups = nn.ModuleList()
         self.resblocks = nn.ModuleList()
         for i in range(cfg.num_upsamples):
             s = specs[f"ups.{i}"]
-            self.ups.append(_WeightNormedConv(s.weight_shape, s.c_out))
+            self.ups.append(_WeightNormedConv(s.weight_shape, s.c_out, _init_weights))
             ch = cfg.stage_channels(i)
             for k, d in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
-                self.resblocks.append(ResBlock(ch, k, d))
-        self.conv_post = _WeightNormedConv(specs["conv_post"].weight_shape, 1)
+                self.resblocks.append(ResBlock(ch, k, d, _init_weights))
+        self.conv_post = _WeightNormedConv(specs["conv_post"].weight_shape, 1, _init_weights)
         self._engine: Optional[GeneratorEngine] = None
         self.eval()
 
@@ -123,6 +138,18 @@ class HiFiGANModel(nn.Module):
                            len(result.missing_keys), result.missing_keys[:3],
                            len(result.unexpected_keys), result.unexpected_keys[:3])
         return result
+
+    def finish_init(self, missing_keys: Sequence[str] = ()) -> None:
+        """After a deferred construction: draws the default init for every layer that still has un-drawn parameters and
+        was not (completely) provided by the checkpoint -- what ``load_state_dict(strict=False)`` leaves untouched in the
+        reference keeps its random init there too (hifigan_pretrained.py:186-190)."""
+        missing_layers = {k.rsplit(".", 1)[0] for k in missing_keys}
+        for name, mod in self.named_modules():
+            if isinstance(mod, _WeightNormedConv) and not mod.initialised:
+                if name in missing_layers:
+                    mod.reset_parameters()
+                mod.initialised = True
+        self._drop_engine()
 
     def to(self, *args, **kwargs):
         """Selects the GPU the engine will live on.  Parameters stay on the host: they are folded
@@ -209,12 +236,26 @@ class HiFiGANGenerator:
         if not self.checkpoint_path.exists():
             raise FileNotFoundError(f"Checkpoint not found: {self.checkpoint_path}")
         logger.info(f"Loading HiFiGAN from: {self.checkpoint_path}")
+        t0 = time.perf_counter()
         checkpoint = _load_checkpoint(self.checkpoint_path)
         state_dict = extract_state_dict(checkpoint)  # ValueError for non-dict, as :199-200
+        t1 = time.perf_counter()
         logger.info("Creating HiFiGAN model with standard architecture...")
-        self.model = HiFiGANModel()  # always the default config, like :186
+        # always the default config, like :186.  The random init is deferred: the checkpoint is about to overwrite it, and
+        # layers it does not provide are drawn afterwards (finish_init) -- same outcome as the reference's strict=False load
+        self.model = HiFiGANModel(_init_weights=False)
+        t2 = time.perf_counter()
         try:
-            self.model.load_state_dict(state_dict, strict=False)
+            result = self.model.load_state_dict(state_dict, strict=False)
+            self.model.finish_init(result.missing_keys)
+            if result.missing_keys:
+                # a layer the checkpoint provides only in part was drawn whole: put the provided part back (in the reference
+                # that part is loaded over the construction-time draw, :186-190)
+                layers = {k.rsplit(".", 1)[0] for k in result.missing_keys}
+                own = self.model.state_dict()
+                part = {k: v for k, v in state_dict.items() if k in own and k.rsplit(".", 1)[0] in layers}
+                if part:
+                    nn.Module.load_state_dict(self.model, part, strict=False)
         except Exception as exc:
             logger.error(f"Failed to load state dict: {exc}")
             raise RuntimeError(
@@ -223,6 +264,10 @@ class HiFiGANGenerator:
         self.model.eval()
         self.device = require_gpu()
         self.model.to(self.device)
+        t3 = time.perf_counter()
+        LAST_LOAD_TIMINGS.clear()
+        LAST_LOAD_TIMINGS.update({"torch_load_ms": 1e3 * (t1 - t0), "model_construct_ms": 1e3 * (t2 - t1),
+                                  "load_state_dict_ms": 1e3 * (t3 - t2)})
         logger.info(f"HiFiGAN loaded successfully on device: {self.device}")
 
     def __call__(self, mel: np.ndarray) -> np.ndarray:

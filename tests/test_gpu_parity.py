@@ -171,8 +171,8 @@ def _mrf_step(lib, xs, ws, bs, rs, B, L, C, dils, plan, mean):
 def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
     """One conv step of the three ResBlock branches (k = 3/7/11; hifigan_pretrained.py:64-71) through the persistent
     MRF kernel, in the library's own plan (0), with full-height tiles (1), half-height tiles (2), one branch per
-    block (3), through the small-problem kernel (4: 16 x 16 jobs on v_mfma_f32_16x16x4_f32) and with (tile, branch)
-    jobs drawn from a counter (5, 6: C >= 128), against the numpy oracle's conv1d_np.  All plans run the same fmaf
+    block (3), through the small-problem kernel (4: 16 x 16 jobs on v_mfma_f32_16x16x4_f32) and with snake-ordered
+    (tile, branch) jobs (5, 6: C >= 128), against the numpy oracle's conv1d_np.  All plans run the same fmaf
     chains: they must agree bit for bit."""
     if plan >= 5 and C < 128:
         pytest.skip("the job mode needs two C_in chunks")
@@ -198,8 +198,8 @@ def test_mrf_step_matches_oracle(lib, B, L, C, dils, use_res, plan):
 
 @pytest.mark.parametrize("B,L,C,dils", [(1, 6100, 256, (1, 1, 1)), (2, 7001, 128, (5, 5, 5)), (3, 1999, 256, (3, 3, 3))])
 def test_mrf_job_mode_agrees_bitwise_when_blocks_draw_many_jobs(lib, B, L, C, dils):
-    """Shapes with more (tile, branch) jobs than the chip has block slots, so that blocks do draw follow-up jobs of other
-    branches and tiles from the counter: plans 5 and 6 against plan 1 (checked against the oracle above), bit for bit."""
+    """Shapes with more (tile, branch) jobs than the chip has block slots, so that blocks do take follow-up jobs of other
+    branches and tiles in later rounds of the snake order: plans 5 and 6 against plan 1 (checked against the oracle above), bit for bit."""
     rng = np.random.default_rng(L + C)
     ks = (3, 7, 11)
     xs = [rng.standard_normal((B, C, L)).astype(np.float32) for _ in ks]
@@ -612,7 +612,7 @@ def test_hipgraph_replay_matches_eager(dev):
     from iris._engine import GeneratorEngine
     from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
     cfg = GeneratorConfig()
-    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0), dev)
+    eng = GeneratorEngine(cfg, seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0), dev, graph_max_frames=0)   # forward = eager
     # (1,300) grows the workspace; (1,64) is re-captured; (3,700) is large enough for the per-forward memset of the
     # MRF kernel's tile counters, which must be part of the captured graph
     for (B, T) in ((1, 64), (2, 33), (1, 300), (1, 64), (3, 700)):

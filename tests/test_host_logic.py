@@ -186,7 +186,7 @@ def test_cabi_exports_every_declared_symbol():
     lib = _native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.iris_hifigan_abi_version() == _native.ABI_VERSION == 3
+    assert lib.iris_hifigan_abi_version() == _native.ABI_VERSION == 4
     assert ctypes.sizeof(_native.Config) == 4 * (3 + 8 + 8 + 1 + 8 + 8 + 64 + 2) + 4
     assert ctypes.sizeof(_native.LaunchRecord) == 40
     assert ctypes.sizeof(_native.WorkspaceMap) == 8 * (2 + 8 + 8 + 1) + 8

@@ -67,7 +67,7 @@ def test_streaming_engine_equals_one_shot_gpu():
 
 
 def test_grouped_chunks_equal_ungrouped():
-    """group_chunks stacks same-width windows along the batch axis: same samples, same order, first chunk alone."""
+    """group_chunks vocodes consecutive chunks as one merged window: same samples, same order, first chunk alone."""
     calls = []
 
     def fwd(m):                                    # +-13-frame dependence like the generator, hop 4
@@ -83,8 +83,8 @@ def test_grouped_chunks_equal_ungrouped():
     assert len(plain) == len(grouped) == 6
     for a, b in zip(plain, grouped):
         assert a.shape == b.shape and np.array_equal(a, b)
-    # chunk 0 alone (269 frames), then chunks 1-3 stacked (6 items of 282 frames), chunk 4 alone (282), last (233)
-    assert calls == [(2, 5, 269), (6, 5, 282), (2, 5, 282), (2, 5, 233)]
+    # chunk 0 alone (frames 0..269), then chunks 1-3 as ONE window (frames 243..1037), then chunks 4-5 (frames 1011..1500)
+    assert calls == [(2, 5, 269), (2, 5, 794), (2, 5, 489)]
     with pytest.raises(ValueError):
         StreamingVocoder(fwd, group_chunks=0)
 

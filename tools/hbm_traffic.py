@@ -7,6 +7,9 @@ bf16 with fused conv pairs at C <= 128: PUMMMMMMUMMMUMMMUMMMO, 21).
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2*FETCH_SIZE*1024;
 WRITE_SIZE*1024 is exact."""
 import collections, csv, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import csrc_digest          # the stamp bench.py's committed_traffic checks (kernel sources this pass was taken on)
 
 def load(path, counter):
     d = collections.OrderedDict()
@@ -40,6 +43,6 @@ for pos, ((kn, grid, f), (kn2, _, w)) in enumerate(zip(fetch, write)):
         mrf.append(t)
 out = {"plan": plan, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes); last forward (%d dispatches)" % n,
        "correction": "gfx950: read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 exact (MI355X_MICROARCH.md, HBM)",
-       "mrf_launches": len(mrf), "mrf_traffic_bytes_per_launch": (sum(mrf) / len(mrf)) if mrf else None, "per_dispatch": rows}
+       "csrc_sha16": csrc_digest(), "mrf_launches": len(mrf), "mrf_traffic_bytes_per_launch": (sum(mrf) / len(mrf)) if mrf else None, "per_dispatch": rows}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("mrf launches %d, traffic/launch %.1f MB, whole forward %.1f MB" % (len(mrf), (sum(mrf) / max(len(mrf), 1)) / 1e6, sum(r["traffic_bytes_corrected"] for r in rows) / 1e6))
