@@ -167,8 +167,8 @@ def cpu_baseline(cfg, sd, mel, budget_s=24.0):
     ATen's convolutions at batch 1 get slower with too many threads, and the best count differs between a 100-frame clip
     and the 1000-frame utterance (round 3 chose on the clip and reported 1.8x less than the box could do).
     Step 1 ranks {8, 16, 32, 64, all} threads on a 100-frame clip (cheap: also the `c1` record, BASELINE.json configs[0] shape);
-    step 2 times the HEADLINE mel itself once at each of the two best counts; step 3 repeats the better one (median of
-    all its runs).  Every timing is in `threads_tried`."""
+    step 2 times the HEADLINE mel itself (after one untimed warm-up run) at each of the two best counts; step 3 repeats the
+    better one (median of all its timed runs).  Every timing is in `threads_tried`."""
     import torch
     from oracle import hifigan_oracle as orc
 
@@ -192,8 +192,9 @@ def cpu_baseline(cfg, sd, mel, budget_s=24.0):
     clip_best = min(tried, key=tried.get)
     candidates = sorted(tried, key=tried.get)[:2]
     full, out_ref = {}, None
-    for n in candidates:                                           # the timed workload itself, once per candidate
+    for n in candidates:                                           # the timed workload itself: one warm-up, one timed run per candidate
         torch.set_num_threads(n)
+        orc.generator_forward_torch(folded, x)                     # (the first run at a new thread count pays the pool's start-up)
         t0 = time.perf_counter()
         out_ref = orc.generator_forward_torch(folded, x)
         full[n] = [time.perf_counter() - t0]

@@ -256,7 +256,9 @@ int32_t iris_hifigan_op_mrf_step(const float* const* x_dev, const float* const* 
  * jobs from a device counter; 2 = the same with a fixed job stride.
  * mean_dev != NULL (modes 1, 2) makes it the LAST pair of a stage: only ((y_0 + y_1) + y_2) / 3 is stored, into mean_dev
  * (hifigan_pretrained.py:131-137; y_dev is then unused).  No y_dev[i] / mean_dev may alias an x_dev[j].
- * Returns IRIS_HIFIGAN_UNSUPPORTED for other shapes. */
+ * The release library carries modes 1 / 2 in the summing form only (as plain pairs they measured slower than mode 0 at
+ * every size and are compiled into the diagnostic build alone): modes 1 / 2 without mean_dev return IRIS_HIFIGAN_UNSUPPORTED
+ * there, as do other shapes. */
 int32_t iris_hifigan_op_mrf_pair(const float* const* x_dev, const float* const* w1_host, const float* const* b1_host,
                                  const float* const* w2_host, const float* const* b2_host, float* const* y_dev,
                                  float* mean_dev, int32_t B, int32_t L, int32_t C, const int32_t* k, const int32_t* dil,

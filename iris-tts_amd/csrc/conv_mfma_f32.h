@@ -478,6 +478,7 @@ inline ConvTile pick_tile(int C_in, int C_out) {
     return t;
 }
 
+#ifndef IRIS_KERNELS_ONLY
 // Fills the derived fields of `a` (n_co_blk, Gp, n_ct) and launches. `nz` = problems or phases.
 inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
@@ -534,5 +535,6 @@ inline hipError_t launch_conv(ConvLaunch& a, int nz, hipStream_t stream) {
 #undef IRIS_LAUNCH
     return hipSuccess;       // (every launch above has reported its own status)
 }
+#endif  // IRIS_KERNELS_ONLY
 
 }  // namespace iris

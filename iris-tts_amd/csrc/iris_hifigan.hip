@@ -26,6 +26,7 @@
 #include "host_parallel.h"
 #include "conv_mfma_f32.h"
 #include "mrf_conv_mfma_f32.h"
+#include "convt_mfma_f32.h"
 #include "mrf_small_f32.h"
 #include "mrf_pair_f32.h"
 #include "mrf_pair_f32_pf.h"
@@ -500,7 +501,17 @@ int forward_f32(iris_hifigan_handle* h, const void* mel_dev, int32_t B, int32_t 
             const int s3_ups = IRIS_DIAG_ENV("IRIS_HIFIGAN_S3UPS", 0);
             if (s3_ups && dtype == IRIS_HIFIGAN_F32_SPLIT && a.in_act == IN_ACT_LRELU && f32s_ups_applicable(h, l, L))
                 TRY(f32s_launch_ups(h, l, a.p[0].x, a.p[0].y, B, L, stream));
-            else
+            else if ((a.in_act == IN_ACT_LRELU || (a.in_act == IN_ACT_MRF_LRELU && nk == 3)) &&
+                     convt_gemm_applicable(l.C_in, l.C_out, l.k, l.u, L, L_out, slope)) {
+                // the whole layer as ONE GEMM [L + 1, 2 C_in] x [2 C_in, u C_out] (convt_mfma_f32.h), bit for bit the polyphase
+                // launches below; its input is one tensor (conv_pre's output, or the MRF mean the previous stage's last step
+                // stored) or the previous stage's three branch outputs, whose mean is then formed while the window is staged
+                ConvtLaunch c; memset(&c, 0, sizeof(c));
+                c.x = a.p[0].x; c.wp = a.p[0].wp; c.bias = a.p[0].bias; c.y = a.p[0].y;
+                if (a.in_act == IN_ACT_MRF_LRELU) { c.x = a.xmrf[0]; c.x1 = a.xmrf[1]; c.x2 = a.xmrf[2]; }
+                c.B = B; c.L_in = L; c.L_out = L_out; c.C_in = l.C_in; c.C_out = l.C_out; c.u = l.u; c.slope = slope;
+                HIP_TRY(launch_convt_gemm(c, l.k, stream));
+            } else
                 HIP_TRY(launch_conv(a, l.u, stream));
             TRY(prof.end());
         }
@@ -875,7 +886,13 @@ int32_t iris_hifigan_op_conv_transpose1d(const float* x_dev, const float* w_host
     a.out_stride = u; a.out_off = -(k - u) / 2; a.z_is_phase = 1;
     a.phase_wp_stride = (int64_t)(phase_floats / 4);
     a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
-    HIP_TRY(launch_conv(a, u, stream));
+    if (in_act && convt_gemm_applicable(C_in, C_out, k, u, L, L * u, slope)) {       // (what the forward launches for this layer)
+        ConvtLaunch c; memset(&c, 0, sizeof(c));
+        c.x = x_dev; c.wp = a.p[0].wp; c.bias = a.p[0].bias; c.y = y_dev;
+        c.B = B; c.L_in = L; c.L_out = L * u; c.C_in = C_in; c.C_out = C_out; c.u = u; c.slope = slope;
+        HIP_TRY(launch_convt_gemm(c, k, stream));
+    } else
+        HIP_TRY(launch_conv(a, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
     IRIS_ABI_END

@@ -8,9 +8,6 @@
 #include "host_parallel.h"
 #include "conv_mfma_bf16.h"
 #include "mrf_pair_bf16.h"
-#ifdef IRIS_MRF_DIAG
-#include "mrf_pair_bf16_pf.h"   // round-3 experiment (persistent + prefetching pair): measured slower, diagnostic builds only
-#endif
 #include "conv_mfma_f32s.h"
 #include "conv_post.h"
 
@@ -323,10 +320,6 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
                 }
                 if (!want_xt && same_k && pair_applicable(pa, nk)) {
                     TRY(prof.begin(2, (int)i, 2 * m + 1, flops, 2.0 * n_el * nk * 5 + wbytes));
-#ifdef IRIS_MRF_DIAG
-                    if (pair_pf_applicable(pa, nk)) HIP_TRY(launch_pair_bf16_pf(pa, nk, stream));
-                    else
-#endif
                     HIP_TRY(launch_pair_bf16(pa, nk, stream));
                     TRY(prof.end());
                     for (int j = 0; j < nk; ++j) cur[j] = pa.p[j].y;
@@ -483,10 +476,6 @@ int32_t iris_hifigan_op_mrf_pair_bf16(const void* const* x_dev, const float* con
         a.p[j].w1 = w1b[j].p; a.p[j].w2 = w2b[j].p;
         a.p[j].b1 = (const float*)b1b[j].p; a.p[j].b2 = (const float*)b2b[j].p;
     }
-#ifdef IRIS_MRF_DIAG
-    if (pair_pf_applicable(a, n_branches)) HIP_TRY(launch_pair_bf16_pf(a, n_branches, stream));
-    else
-#endif
     HIP_TRY(launch_pair_bf16(a, n_branches, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;

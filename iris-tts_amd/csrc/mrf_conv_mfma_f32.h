@@ -54,6 +54,12 @@ namespace iris {
 #ifndef IRIS_MRF_MINWAVES
 #define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
 #endif
+#ifndef IRIS_MRF_LEAN
+#define IRIS_MRF_LEAN 0          // 1 = wide stages (C >= 128): tile-serial launches run the LEAN form at three blocks per CU (A/B builds)
+#endif
+#ifndef IRIS_MRF_LEAN_DB
+#define IRIS_MRF_LEAN_DB 4       // weight fragments in flight in the LEAN form (4: 167 VGPRs; 3: 163; 2: 159 -- no spills)
+#endif
 #ifndef IRIS_MRF_DBUF
 #define IRIS_MRF_DBUF 0          // 1 = two LDS window buffers for the wide stages (see DBUF below): measured, no gain -- off
 #endif
@@ -90,9 +96,20 @@ __device__ __forceinline__ T* uniform_ptr_mrf(T* p) {     // a block-uniform poi
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR>
-__global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
+// MINW = waves per SIMD the register allocator must leave room for (= blocks per CU: a block is one wave per SIMD).
+// MINW >= 3 selects the LEAN register diet (round 4; 168 VGPRs at full tile height instead of 223-240):
+//   * the biases of the three branches live in an LDS table behind the window (written once per block) and are read in
+//     the epilogue, instead of 16 registers held over a whole branch;
+//   * the epilogue stores straight from the accumulators (or the running MRF sum) -- nothing rewrites those registers
+//     before the next branch zeroes them, behind the LDS write and two barriers -- instead of from a 32-register copy;
+//   * the activation fragments are single-buffered: the MFMAs of a group are issued m-major (all four k-pairs of row tile 0,
+//     then of row tile 1), and row tile m's fragment of the NEXT group is requested as soon as its four MFMAs have issued
+//     (256 cycles ahead of its use).  v_mfma_f32_32x32x2_f32 chains on one accumulator back to back (SrcC forwarding).
+// Every output element is the same fmaf chain in the same order as in the MINW = 2 form: bit-identical.
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR, int MINW = IRIS_MRF_MINWAVES>
+__global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool LEAN = MINW >= 3;
     constexpr int S = CIC + 4;
     constexpr int QPR = CIC / 4;
     constexpr int GPC = CIC / 8;
@@ -127,6 +144,17 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
     constexpr int ablate = 0;
 #endif
     const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
+    // LEAN: [3][C_out] biases behind the window(s) and the next-tile word (launch_mrf_conv sizes the dynamic LDS for it)
+    float* const lds_bias = lds + (DBUF ? 2 : 1) * BUF_FLOATS + 4;
+    if constexpr (LEAN) {
+        const int q = a.C_out >> 2;                           // C_out % 4 == 0 (mrf_kernel_applicable)
+        for (int i = tid; i < 3 * q; i += 256) {
+            const int z = i / q, c4 = i - z * q;
+            const float* bp = z == 0 ? a.p[0].bias : (z == 1 ? a.p[1].bias : a.p[2].bias);
+            *reinterpret_cast<f32x4*>(lds_bias + z * a.C_out + 4 * c4) = *reinterpret_cast<const f32x4*>(bp + 4 * c4);
+        }
+        // (visible to every wave after the prologue's barrier; the table is never rewritten)
+    }
 #ifdef IRIS_MRF_BLOCKLOG
     // diagnostic build only (make variant NAME=blocklog EXTRA=-DIRIS_MRF_BLOCKLOG): every block leaves its start / end time on the
     // constant 100 MHz clock and the CU it ran on, for a per-CU timeline of the launch
@@ -246,9 +274,11 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
         // loaded here, not in the epilogue: vmcnt retires in order, so a load issued in the epilogue
         // would have to wait for every prefetch issued by the last MFMA groups
         f32x4 bias4[4];                                  // channels co4 + 8g + {0..3}
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + (t.co4 + 8 * g < a.C_out ? t.co4 + 8 * g : 0));
+            for (int g = 0; g < 4; ++g)
+                bias4[g] = *reinterpret_cast<const f32x4*>(p.bias + (t.co4 + 8 * g < a.C_out ? t.co4 + 8 * g : 0));
+        }
         constexpr int NRES = MT * 4;                     // 16-byte residual pieces per lane: (m, g)
         constexpr int RPG = (NRES + NG - 1) / NG;        // residual loads issued per MFMA group
         f32x4 resv[NRES];
@@ -269,7 +299,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
             if (last) nj = get_next();
             const bool next_valid = nj.valid;
             const bool has_next = !last || next_valid;
-            f32x4 outv[MT * 4];        // store data of this branch's epilogue (see keep-alive below)
+            f32x4 outv[LEAN ? 1 : MT * 4];        // store data of this branch's epilogue (see keep-alive below); LEAN: stores read acc / sumv
             bool stored = false;
             // the phase that follows: next chunk of this branch, or chunk 0 of the next job
             const bool cross = last && next_valid;
@@ -295,7 +325,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                     return buf_load4(wr, t.wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
                 return buf_load4(wrn, voff_next, wsoffn + (unsigned)(n - NG) * wbytes_group);   // n-NG < DB <= GPC: tap 0
             };
-            f32x4 av[2][MT];
+            f32x4 av[LEAN ? 1 : 2][MT];
             IRIS_STAMP(ts0);
 #pragma unroll
             for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(a_ptr(0) + m * 32 * S);
@@ -321,6 +351,30 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 if constexpr (DBUF) {
                     static_assert(!DBUF || NG >= 2 * NQ, "a phase must be long enough to request and write the next window");
                     if (n >= NG - NQ) stage_write_one(n - (NG - NQ), lds_wr_n);
+                }
+                if constexpr (LEAN) {
+                    // m-major: row tile m's four MFMAs, then its fragment of group n + 1 into the same registers
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bw[n % (DB + 1)][e], av[0][m][e], acc[m], 0, 0, 0);
+                        if (n + 1 < NG) av[0][m] = *reinterpret_cast<const f32x4*>(a_ptr(n + 1) + m * 32 * S);
+                    }
+                    // schedule: per row tile 4 MFMAs with one memory request behind each of the first ones, then the DS read
+                    const int n_vm = 1 + (n < NQ ? 1 : 0) + ((n * RPG < NRES) ? ((NRES - n * RPG) < RPG ? (NRES - n * RPG) : RPG) : 0);
+                    int vm_left = n_vm;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (vm_left > 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); --vm_left; }
+                        }
+                        if (n + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
                 }
                 if (n + 1 < NG) {
 #pragma unroll
@@ -372,6 +426,11 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 // registers two instructions later, and with the store path busy (8 stores per wave, two
                 // blocks per CU) stores were observed to pick up the NEXT piece's values in lanes 12-15
                 // of each 16-lane row -- wrong results only when two blocks shared a CU.
+                if constexpr (LEAN) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        bias4[g] = *reinterpret_cast<const f32x4*>(lds_bias + PI * a.C_out + (t.co4 + 8 * g < a.C_out ? t.co4 + 8 * g : 0));
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -399,7 +458,21 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!SUM || PI == 0) {
+                if constexpr (LEAN && (!SUM || PI == 0)) {
+                    // straight from the accumulators / the running sum: these registers are next written by the zero-init of
+                    // the following branch, i.e. behind the LDS write and both barriers below (keep-alive there)
+                    const __amdgpu_buffer_rsrc_t yo = SUM ? make_rsrc(a.sum_y + t.batch_off, tensor_bytes) : yr;
+#pragma unroll
+                    for (int idx = 0; idx < MT * 4; ++idx) {
+                        const f32x16& src = SUM ? sumv[idx / 4] : acc[idx / 4];
+                        const int g = idx % 4;
+                        const f32x4 v = {src[4 * g + 0], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
+                        if (!(ablate & 4) || v.x == 1.2345e-30f)
+                            buf_store4(v, yo, t.ovoff4, (unsigned)((idx / 4) * 32 * C + 8 * g) * 4u);
+                    }
+                    asm volatile("s_nop 1");
+                    stored = true;
+                } else if constexpr (!SUM || PI == 0) {
                     const __amdgpu_buffer_rsrc_t yo = SUM ? make_rsrc(a.sum_y + t.batch_off, tensor_bytes) : yr;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -429,8 +502,17 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #endif
             if (DBUF && has_next) {
                 if (stored) {
+                    if constexpr (LEAN) {
 #pragma unroll
-                    for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));   // (keep-alive, see below)
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {      // (one register per statement: a 64-byte "v" operand is not valid in the host pass)
+                                if constexpr (SUM) asm volatile("" :: "v"(sumv[m][r])); else asm volatile("" :: "v"(acc[m][r]));
+                            }
+                    } else {
+#pragma unroll
+                        for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));   // (keep-alive, see below)
+                    }
                 }
                 __syncthreads();          // every wave is done reading this window AND has written its share of the next one
                 cur ^= 1;
@@ -444,8 +526,17 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
                 if (stored) {
                     // keep the epilogue's store-data registers allocated until here: nothing may be
                     // written into them right behind the buffer_store_dwordx4s that read them
+                    if constexpr (LEAN) {
 #pragma unroll
-                    for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {      // (one register per statement: a 64-byte "v" operand is not valid in the host pass)
+                                if constexpr (SUM) asm volatile("" :: "v"(sumv[m][r])); else asm volatile("" :: "v"(acc[m][r]));
+                            }
+                    } else {
+#pragma unroll
+                        for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));
+                    }
                 }
                 __syncthreads();
                 IRIS_STAMP(ts5);
@@ -598,6 +689,7 @@ __global__ void __launch_bounds__(256, IRIS_MRF_MINWAVES) mrf_conv_mfma_f32_kern
 #endif
 }
 
+#ifndef IRIS_KERNELS_ONLY     // (register-count probes instantiate single kernels: tools/kernel_probe.sh)
 // True when the grouped launch `a` (nz problems) can take the MRF kernel.
 inline bool mrf_kernel_applicable(const ConvLaunch& a, int nz) {
     if (a.z_is_phase || a.x_channels_first || a.in_act == IN_ACT_MRF_LRELU) return false;
@@ -653,10 +745,11 @@ inline int mrf_cu_count() { return device_cu_count(); }
 // 3 the round-1 rule, 4 the small-problem kernel, 5 / 6 snake-ordered jobs at half / full tile height.
 constexpr double kLoneSpeed = 1.8, kHalfHeightCost = 1.06, kSnakeCost = 1.04, kFixedRangeCost = 1.02;
 
-inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_env, int per_cu) {
+inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_env, int per_cu, bool lean = false) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     const int n_cu = mrf_cu_count();
     const long long slots = (long long)n_cu * per_cu;
+    const long long slots_lean = (long long)n_cu * 3;       // the LEAN form of the full-height tile-serial kernel: three blocks per CU
     const int n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     auto tiles = [&](int MT) { return (long long)((a.L_out + t.WT * MT * 32 - 1) / (t.WT * MT * 32)) * n_co_blk * a.B; };
     static const int cost[3] = {3, 7, 11};            // branch 0, 1, 2
@@ -680,9 +773,10 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
         return worst;
     };
     // tile-serial
-    auto serial_grid = [&](long long n) { long long g = n < slots ? n : slots; if (g < 1) g = 1; const long long r = (n + g - 1) / g; return (n + r - 1) / r; };
+    auto serial_grid = [&](long long n, int MT = 1) { const long long sl = (lean && MT == 2) ? slots_lean : slots;
+                                                      long long g = n < sl ? n : sl; if (g < 1) g = 1; const long long r = (n + g - 1) / g; return (n + r - 1) / r; };
     auto serial = [&](int MT) -> double {
-        const long long n = tiles(MT), g = serial_grid(n), rounds = (n + g - 1) / g, full = n - (rounds - 1) * g;
+        const long long n = tiles(MT), g = serial_grid(n, MT), rounds = (n + g - 1) / g, full = n - (rounds - 1) * g;
         return cu_time(g, [&](long long i) { return (double)((i < full ? rounds : rounds - 1) * 21 * MT); }) * (MT == 1 ? kHalfHeightCost : 1.0);
     };
     // fixed ranges: smallest M with sum_c ceil(n / floor(M / cost_c)) <= limit
@@ -781,7 +875,7 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
         pl.zb1 = (int)nb[2]; pl.zb2 = (int)(nb[2] + nb[1]); pl.grid = nb[2] + nb[1] + nb[0];
         return pl;
     }
-    pl.grid = serial_grid(pl.n_tiles);
+    pl.grid = serial_grid(pl.n_tiles, pl.MT);
     return pl;
 }
 
@@ -789,9 +883,11 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
 inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
     const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", IRIS_MRF_FORCE_PLAN);
+    // LEAN form (three blocks per CU): the tile-serial, non-summing launches of the wide stages
+    const bool lean = IRIS_MRF_LEAN && a.sum_y == nullptr && pick_tile(a.C_in, a.C_out).WT == 1;
     const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
 #ifdef IRIS_MRF_DIAG
-    return mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);       // (environment switches may change between calls)
+    return mrf_plan_uncached(a, allow_zpar, plan_env, per_cu, lean);       // (environment switches may change between calls)
 #else
     struct Entry { int key[8]; MrfPlan pl; bool used; };
     static thread_local Entry cache[16] = {};
@@ -803,7 +899,7 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     Entry& e = cache[next];
     next = (next + 1) % 16;
     memcpy(e.key, key, sizeof(key));
-    e.pl = mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);
+    e.pl = mrf_plan_uncached(a, allow_zpar, plan_env, per_cu, lean);
     e.used = true;
     return e.pl;
 #endif
@@ -823,7 +919,9 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
     if (pl.small) return launch_mrf_small(a, nz, stream);
     const int T_BLK = t.WT * pl.MT * 32;
+    const bool lean = IRIS_MRF_LEAN && a.sum_y == nullptr && t.WT == 1 && pl.MT == 2 && !pl.zpar && !pl.zdyn;
     size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;         // + next-tile word
+    if (lean) lds_bytes += (size_t)3 * a.C_out * sizeof(float);                                   // + the bias table of the LEAN form
     if (t.WT == 1 && IRIS_MRF_DBUF) {    // two window buffers of NQ * RPI rows (see the kernel)
         const int qpr = t.CIC / 4, nq = ((T_BLK + kMrfSpanMax) * qpr + 255) / 256, rpi = 256 / qpr;
         lds_bytes = (size_t)2 * nq * rpi * (t.CIC + 4) * sizeof(float) + 16;
@@ -840,11 +938,17 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         auto kfn = __VA_ARGS__;                                                                   \
         { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
     } while (0)
+    // (the LEAN form exists for the wide tile only: IRIS_MRF_LAUNCH_LEAN expands to nothing for the others)
+#define IRIS_MRF_LAUNCH_LEAN(WT_, WC_, CIC_) IRIS_MRF_LAUNCH_LEAN_##WT_(WC_, CIC_)
+#define IRIS_MRF_LAUNCH_LEAN_1(WC_, CIC_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 2, CIC_, IRIS_MRF_LEAN_DB, 3, 7, 11, false, 0, 3>)
+#define IRIS_MRF_LAUNCH_LEAN_2(WC_, CIC_) return hipErrorInvalidValue
+#define IRIS_MRF_LAUNCH_LEAN_4(WC_, CIC_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_, D1_, D2_)                                                       \
     do {                                                                                          \
         if (pl.MT == 2) {                                                                         \
             if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 2>);   \
             else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 11, 7, 3, true, 0>);   \
+            else if (lean) IRIS_MRF_LAUNCH_LEAN(WT_, WC_, CIC_);                                           \
             else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 0>);  \
         } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 11, 7, 3, true, 0>);   \
         else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 2>);   \
@@ -912,8 +1016,13 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB
+#undef IRIS_MRF_LAUNCH_LEAN
+#undef IRIS_MRF_LAUNCH_LEAN_1
+#undef IRIS_MRF_LAUNCH_LEAN_2
+#undef IRIS_MRF_LAUNCH_LEAN_4
 #undef IRIS_MRF_LAUNCH_K
     return hipSuccess;       // (every launch above has reported its own status)
 }
+#endif  // IRIS_KERNELS_ONLY
 
 }  // namespace iris

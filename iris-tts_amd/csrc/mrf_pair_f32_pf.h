@@ -442,6 +442,9 @@ inline bool pair_pf_f32_applicable(const PairLaunchF32& a, int nz, bool sum) {
         const long long tiles = (a.L + (t.M - (kmax - 1)) - 1) / (t.M - (kmax - 1));
         if (tiles * a.B * nz > 0x3fffffffLL) return false;
     }
+#ifndef IRIS_MRF_DIAG
+    if (!sum) return false;        // release build: only the summing form exists (the plain persistent pairs measured 3-5 % slower)
+#endif
     return IRIS_DIAG_ENV("IRIS_HIFIGAN_PAIR_PF", IRIS_PAIR_F32_PF_DEFAULT) != 0;
 }
 
@@ -485,16 +488,25 @@ inline hipError_t launch_pair_f32_pf(const PairLaunchF32& src, int nz, float* su
     a.bias_off = (int)((window_floats + 3) & ~(size_t)3);
     const size_t lds_bytes = ((size_t)a.bias_off + (size_t)nz * 2 * a.C + 4) * sizeof(float);      // + the next-job word
     dim3 grid((unsigned)G, 1u, 1u), block(256);
+    // The non-summing instantiations (plain persistent pairs: 3-5 % slower than one block per job at every size, profiles/r03_notes.md)
+    // exist in the diagnostic build only; the release library carries the summing form alone.
+#ifdef IRIS_MRF_DIAG
+#define IRIS_PAIR_PF_F32_PLAIN(WT_, WC_, MT_, C_, MINB_)                                                                 \
+        return ::iris::launch_kernel_named("mrf_pair_f32_pf_kernel", mrf_pair_f32_pf_kernel<WT_, WC_, MT_, C_, MINB_, false>,                 \
+                                           grid, block, lds_bytes, stream, a);
+#else
+#define IRIS_PAIR_PF_F32_PLAIN(WT_, WC_, MT_, C_, MINB_) return hipErrorNotSupported;
+#endif
 #define IRIS_PAIR_PF_F32_CASE(WT_, WC_, MT_, C_, MINB_)                                                                  \
     if (a.C == C_ && t.WT == WT_ && t.MT == MT_) {                                                                       \
         if (sum_y) return ::iris::launch_kernel_named("mrf_pair_f32_pf_kernel<sum>", mrf_pair_f32_pf_kernel<WT_, WC_, MT_, C_, MINB_, true>,  \
                                                       grid, block, lds_bytes, stream, a);                                \
-        return ::iris::launch_kernel_named("mrf_pair_f32_pf_kernel", mrf_pair_f32_pf_kernel<WT_, WC_, MT_, C_, MINB_, false>,                 \
-                                           grid, block, lds_bytes, stream, a);                                           \
+        IRIS_PAIR_PF_F32_PLAIN(WT_, WC_, MT_, C_, MINB_)                                                                 \
     }
     IRIS_PAIR_PF_F32_CASE(4, 1, 1, 32, 4)
     IRIS_PAIR_PF_F32_CASE(2, 2, 2, 64, 2)
 #undef IRIS_PAIR_PF_F32_CASE
+#undef IRIS_PAIR_PF_F32_PLAIN
     return hipErrorInvalidValue;
 }
 

@@ -265,12 +265,19 @@ def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils, mo
             ctypes.c_void_p(mean_tensor.data_ptr()) if mean_tensor is not None else None,
             B, L, C, (ctypes.c_int32 * 3)(*ks), (ctypes.c_int32 * 3)(*dils), 0.1, m, None)
 
-    _check("op_mrf_pair", pair(yd, None, mode))
-    got = [t.cpu().numpy().transpose(0, 2, 1) for t in yd]
     _, xt = _mrf_step(lib, xs, w1, b1, None, B, L, C, dils, 0, mean=False)
     _, sep = _mrf_step(lib, xt, w2, b2, xs, B, L, C, (1, 1, 1), 0, mean=False)
     small = B * L * C <= 400_000                         # (the numpy oracle is slow: large cases are checked bit for bit only)
-    for j in range(3):
+    rc = pair(yd, None, mode)
+    if mode >= 1 and rc == 4:
+        # IRIS_HIFIGAN_UNSUPPORTED: the release library carries the persistent kernel in its summing form only (the plain
+        # persistent pairs measured slower and live in the diagnostic build) -- the summing form is checked below
+        plain = False
+    else:
+        _check("op_mrf_pair", rc)
+        plain = True
+    got = [t.cpu().numpy().transpose(0, 2, 1) for t in yd]
+    for j in range(3 if plain else 0):
         assert np.isfinite(got[j]).all()
         if small:
             want_xt = orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), w1[j], b1[j], dils[j]).astype(np.float32)
@@ -280,12 +287,18 @@ def test_mrf_fused_pair_matches_oracle_and_separate_steps(lib, B, L, C, dils, mo
     # aliased buffers are refused (a block's window overlaps the rows its neighbours write)
     assert pair(xd, None, mode) != 0
     if mode >= 1:
+        if small:                                       # (the oracle itself, not only the separate launches)
+            want = [orc.conv1d_np(orc.lrelu_np(orc.conv1d_np(orc.lrelu_np(xs[j], 0.1), w1[j], b1[j], dils[j]).astype(np.float32), 0.1),
+                                  w2[j], b2[j], 1) + xs[j] for j in range(3)]
+            want_mean = ((want[0] + want[1]) + want[2]) / 3.0
         # the same launch as the LAST pair of a stage: only ((y_0 + y_1) + y_2) / 3 is stored (hifigan_pretrained.py:131-137),
         # bit for bit the reference-order sum of the separate branch outputs
         mean = torch.full((B, L, C), float("nan"), device="cuda")
         _check("op_mrf_pair (summing)", pair(None, mean, mode))
         got_mean = mean.cpu().numpy().transpose(0, 2, 1)
         assert np.array_equal(got_mean, ((sep[0] + sep[1]) + sep[2]) / np.float32(3))
+        if small:
+            assert np.abs(got_mean - want_mean).max() <= 2 * TOL_LAYER * max(1.0, np.abs(want_mean).max())
         assert pair(None, xd[1], mode) != 0             # the mean may not overwrite an input either
     else:
         assert pair(None, torch.empty((B, L, C), device="cuda"), 0) == 4      # IRIS_HIFIGAN_UNSUPPORTED: mode 0 cannot sum
