@@ -607,8 +607,8 @@ def rank_main(args):
                       "engine_default_is_graph": bool(frames <= eng.graph_max_frames),
                       "note": "ms / roofline_frac: eager launches with the live per-layer-group events; ms_hipgraph_replay: the same "
                               "launches replayed as one hipGraph (static buffers, no events); ms_engine_default: "
-                              "GeneratorEngine.forward as the drop-in wrappers call it (graph replay + copy-out up to "
-                              f"{eng.graph_max_frames} frames, eager above)"})
+                              "GeneratorEngine.forward as the drop-in wrappers call it (eager launches, no events; graph replay + "
+                              f"copy-out only up to graph_max_frames = {eng.graph_max_frames} frames)"})
         out["grid"] = g
         # ---- host-inclusive: numpy in -> numpy out, PCIe both ways, synchronous (never `value`) --------------------------
         def host_call(x):

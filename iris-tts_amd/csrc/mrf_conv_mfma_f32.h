@@ -54,11 +54,8 @@ namespace iris {
 #ifndef IRIS_MRF_MINWAVES
 #define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
 #endif
-#ifndef IRIS_MRF_LEAN
-#define IRIS_MRF_LEAN 0          // 1 = wide stages (C >= 128): tile-serial launches run the LEAN form at three blocks per CU (A/B builds)
-#endif
-#ifndef IRIS_MRF_LEAN_DB
-#define IRIS_MRF_LEAN_DB 4       // weight fragments in flight in the LEAN form (4: 167 VGPRs; 3: 163; 2: 159 -- no spills)
+#ifndef IRIS_MRF_TALL
+#define IRIS_MRF_TALL 1          // wide stages: tile-serial launches with enough tiles run 128-row tiles (MT = 4, LEAN registers); A/B builds: 0
 #endif
 #ifndef IRIS_MRF_DBUF
 #define IRIS_MRF_DBUF 0          // 1 = two LDS window buffers for the wide stages (see DBUF below): measured, no gain -- off
@@ -97,7 +94,8 @@ __device__ __forceinline__ T* uniform_ptr_mrf(T* p) {     // a block-uniform poi
 }
 
 // MINW = waves per SIMD the register allocator must leave room for (= blocks per CU: a block is one wave per SIMD).
-// MINW >= 3 selects the LEAN register diet (round 4; 168 VGPRs at full tile height instead of 223-240):
+// LEANP selects the LEAN register diet (round 4; 64-row tiles: 167 VGPRs instead of 223-240 -- which bought NOTHING as a third
+// block per CU, profiles/r04_notes.md -- and what makes the 128-row tile, MT = 4, fit in 251):
 //   * the biases of the three branches live in an LDS table behind the window (written once per block) and are read in
 //     the epilogue, instead of 16 registers held over a whole branch;
 //   * the epilogue stores straight from the accumulators (or the running MRF sum) -- nothing rewrites those registers
@@ -106,10 +104,10 @@ __device__ __forceinline__ T* uniform_ptr_mrf(T* p) {     // a block-uniform poi
 //     then of row tile 1), and row tile m's fragment of the NEXT group is requested as soon as its four MFMAs have issued
 //     (256 cycles ahead of its use).  v_mfma_f32_32x32x2_f32 chains on one accumulator back to back (SrcC forwarding).
 // Every output element is the same fmaf chain in the same order as in the MINW = 2 form: bit-identical.
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR, int MINW = IRIS_MRF_MINWAVES>
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR, int MINW = IRIS_MRF_MINWAVES, bool LEANP = (MINW >= 3)>
 __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr bool LEAN = MINW >= 3;
+    constexpr bool LEAN = LEANP;
     constexpr int S = CIC + 4;
     constexpr int QPR = CIC / 4;
     constexpr int GPC = CIC / 8;
@@ -745,11 +743,10 @@ inline int mrf_cu_count() { return device_cu_count(); }
 // 3 the round-1 rule, 4 the small-problem kernel, 5 / 6 snake-ordered jobs at half / full tile height.
 constexpr double kLoneSpeed = 1.8, kHalfHeightCost = 1.06, kSnakeCost = 1.04, kFixedRangeCost = 1.02;
 
-inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_env, int per_cu, bool lean = false) {
+inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_env, int per_cu) {
     const ConvTile t = pick_tile(a.C_in, a.C_out);
     const int n_cu = mrf_cu_count();
     const long long slots = (long long)n_cu * per_cu;
-    const long long slots_lean = (long long)n_cu * 3;       // the LEAN form of the full-height tile-serial kernel: three blocks per CU
     const int n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     auto tiles = [&](int MT) { return (long long)((a.L_out + t.WT * MT * 32 - 1) / (t.WT * MT * 32)) * n_co_blk * a.B; };
     static const int cost[3] = {3, 7, 11};            // branch 0, 1, 2
@@ -773,10 +770,9 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
         return worst;
     };
     // tile-serial
-    auto serial_grid = [&](long long n, int MT = 1) { const long long sl = (lean && MT == 2) ? slots_lean : slots;
-                                                      long long g = n < sl ? n : sl; if (g < 1) g = 1; const long long r = (n + g - 1) / g; return (n + r - 1) / r; };
+    auto serial_grid = [&](long long n) { long long g = n < slots ? n : slots; if (g < 1) g = 1; const long long r = (n + g - 1) / g; return (n + r - 1) / r; };
     auto serial = [&](int MT) -> double {
-        const long long n = tiles(MT), g = serial_grid(n, MT), rounds = (n + g - 1) / g, full = n - (rounds - 1) * g;
+        const long long n = tiles(MT), g = serial_grid(n), rounds = (n + g - 1) / g, full = n - (rounds - 1) * g;
         return cu_time(g, [&](long long i) { return (double)((i < full ? rounds : rounds - 1) * 21 * MT); }) * (MT == 1 ? kHalfHeightCost : 1.0);
     };
     // fixed ranges: smallest M with sum_c ceil(n / floor(M / cost_c)) <= limit
@@ -875,7 +871,7 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
         pl.zb1 = (int)nb[2]; pl.zb2 = (int)(nb[2] + nb[1]); pl.grid = nb[2] + nb[1] + nb[0];
         return pl;
     }
-    pl.grid = serial_grid(pl.n_tiles, pl.MT);
+    pl.grid = serial_grid(pl.n_tiles);
     return pl;
 }
 
@@ -883,11 +879,9 @@ inline MrfPlan mrf_plan_uncached(const ConvLaunch& a, bool allow_zpar, int plan_
 inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     const int per_cu_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_PERCU", 0);
     const int plan_env = force >= 0 ? force : IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFPLAN", IRIS_MRF_FORCE_PLAN);
-    // LEAN form (three blocks per CU): the tile-serial, non-summing launches of the wide stages
-    const bool lean = IRIS_MRF_LEAN && a.sum_y == nullptr && pick_tile(a.C_in, a.C_out).WT == 1;
     const int per_cu = per_cu_env > 0 ? per_cu_env : IRIS_MRF_MINWAVES;
 #ifdef IRIS_MRF_DIAG
-    return mrf_plan_uncached(a, allow_zpar, plan_env, per_cu, lean);       // (environment switches may change between calls)
+    return mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);       // (environment switches may change between calls)
 #else
     struct Entry { int key[8]; MrfPlan pl; bool used; };
     static thread_local Entry cache[16] = {};
@@ -899,7 +893,7 @@ inline MrfPlan mrf_plan(const ConvLaunch& a, bool allow_zpar, int force = -1) {
     Entry& e = cache[next];
     next = (next + 1) % 16;
     memcpy(e.key, key, sizeof(key));
-    e.pl = mrf_plan_uncached(a, allow_zpar, plan_env, per_cu, lean);
+    e.pl = mrf_plan_uncached(a, allow_zpar, plan_env, per_cu);
     e.used = true;
     return e.pl;
 #endif
@@ -918,8 +912,22 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     a.stagger_mod = mrf_cu_count();
     const MrfPlan pl = mrf_plan(a, a.sum_y == nullptr, force_plan);
     if (pl.small) return launch_mrf_small(a, nz, stream);
-    const int T_BLK = t.WT * pl.MT * 32;
-    const bool lean = IRIS_MRF_LEAN && a.sum_y == nullptr && t.WT == 1 && pl.MT == 2 && !pl.zpar && !pl.zdyn;
+    // 128-row tiles (round 4) for the tile-serial, non-summing launches of the wide stages: each weight fragment feeds four row
+    // tiles instead of two and a tile has half the phase transitions per MFMA (the kernel's LEAN register form: 251 VGPRs).
+    // Taken when it leaves no block slot emptier than the 64-row plan does: batch 1 x 1000 frames, C = 128: 500 blocks of one
+    // 128-row tile instead of two 64-row tiles, 335 -> 328 us per step; 4 x 1000: -3 %; neutral from ~16,000 frames on.
+    MrfPlan plt = pl;
+    bool tall = false;
+    if (IRIS_DIAG_ENV("IRIS_HIFIGAN_MRFTALL", IRIS_MRF_TALL) && a.sum_y == nullptr && t.WT == 1 && pl.MT == 2 && !pl.zpar && !pl.zdyn && !pl.small) {
+        const long long n4 = (long long)((a.L_out + 127) / 128) * a.n_co_blk * a.B;
+        const long long slots = 2LL * mrf_cu_count();
+        long long g4 = n4 < slots ? n4 : slots; if (g4 < 1) g4 = 1;
+        const long long r4 = (n4 + g4 - 1) / g4; g4 = (n4 + r4 - 1) / r4;
+        if (g4 >= pl.grid - 16) { tall = true; plt.MT = 4; plt.n_tiles = n4; plt.grid = g4; }
+    }
+    const MrfPlan& plx = plt;
+    const int T_BLK = t.WT * plx.MT * 32;
+    const bool lean = tall;
     size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;         // + next-tile word
     if (lean) lds_bytes += (size_t)3 * a.C_out * sizeof(float);                                   // + the bias table of the LEAN form
     if (t.WT == 1 && IRIS_MRF_DBUF) {    // two window buffers of NQ * RPI rows (see the kernel)
@@ -928,9 +936,9 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     }
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
     const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
-    if (!dyn_env || pl.zpar || pl.n_tiles < 4 * pl.grid) a.dyn_counter = nullptr;
+    if (!dyn_env || pl.zpar || plx.n_tiles < 4 * plx.grid) a.dyn_counter = nullptr;
     a.zb1 = pl.zb1; a.zb2 = pl.zb2;
-    const long long n_tiles = pl.n_tiles, g = pl.grid;
+    const long long n_tiles = plx.n_tiles, g = plx.grid;
     if (n_tiles > 0x7fffffffLL / 3) return hipErrorInvalidValue;
     dim3 grid((unsigned)g, 1u, 1u), block(256);
 #define IRIS_MRF_LAUNCH_K(...)                                                                    \
@@ -938,17 +946,17 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         auto kfn = __VA_ARGS__;                                                                   \
         { const hipError_t e__ = ::iris::launch_kernel_named(#__VA_ARGS__, kfn, grid, block, lds_bytes, stream, a); if (e__ != hipSuccess) return e__; } \
     } while (0)
-    // (the LEAN form exists for the wide tile only: IRIS_MRF_LAUNCH_LEAN expands to nothing for the others)
-#define IRIS_MRF_LAUNCH_LEAN(WT_, WC_, CIC_) IRIS_MRF_LAUNCH_LEAN_##WT_(WC_, CIC_)
-#define IRIS_MRF_LAUNCH_LEAN_1(WC_, CIC_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 2, CIC_, IRIS_MRF_LEAN_DB, 3, 7, 11, false, 0, 3>)
-#define IRIS_MRF_LAUNCH_LEAN_2(WC_, CIC_) return hipErrorInvalidValue
-#define IRIS_MRF_LAUNCH_LEAN_4(WC_, CIC_) return hipErrorInvalidValue
+    // (the 128-row form exists for the wide tile only: IRIS_MRF_LAUNCH_TALL refuses the others)
+#define IRIS_MRF_LAUNCH_TALL(WT_, WC_, CIC_) IRIS_MRF_LAUNCH_TALL_##WT_(WC_, CIC_)
+#define IRIS_MRF_LAUNCH_TALL_1(WC_, CIC_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 4, CIC_, 2, 3, 7, 11, false, 0, 2, true>)
+#define IRIS_MRF_LAUNCH_TALL_2(WC_, CIC_) return hipErrorInvalidValue
+#define IRIS_MRF_LAUNCH_TALL_4(WC_, CIC_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_, D1_, D2_)                                                       \
     do {                                                                                          \
-        if (pl.MT == 2) {                                                                         \
+        if (tall) IRIS_MRF_LAUNCH_TALL(WT_, WC_, CIC_);                                            \
+        else if (pl.MT == 2) {                                                                    \
             if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 2>);   \
             else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 11, 7, 3, true, 0>);   \
-            else if (lean) IRIS_MRF_LAUNCH_LEAN(WT_, WC_, CIC_);                                           \
             else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 0>);  \
         } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 11, 7, 3, true, 0>);   \
         else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 2>);   \
@@ -1016,10 +1024,10 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB
-#undef IRIS_MRF_LAUNCH_LEAN
-#undef IRIS_MRF_LAUNCH_LEAN_1
-#undef IRIS_MRF_LAUNCH_LEAN_2
-#undef IRIS_MRF_LAUNCH_LEAN_4
+#undef IRIS_MRF_LAUNCH_TALL
+#undef IRIS_MRF_LAUNCH_TALL_1
+#undef IRIS_MRF_LAUNCH_TALL_2
+#undef IRIS_MRF_LAUNCH_TALL_4
 #undef IRIS_MRF_LAUNCH_K
     return hipSuccess;       // (every launch above has reported its own status)
 }

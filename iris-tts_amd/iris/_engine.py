@@ -51,9 +51,12 @@ class GeneratorEngine:
     calls select the engine's device themselves (``include/iris_hifigan.h``), so an engine may live on a GPU
     that is not the caller's current device."""
 
-    # forward() replays a captured hipGraph instead of issuing 24-30 launches when batch * frames is at most this many mel
-    # frames (the forward is then launch-/latency-bound: 0.84 -> 0.81 ms at 100 frames, 1.5 % at 282, nothing from ~700 on)
-    GRAPH_MAX_FRAMES = 384
+    # forward() can replay a captured hipGraph instead of issuing 24-30 launches when batch * frames is at most
+    # graph_max_frames.  OFF by default (0): measured on MI355X / ROCm 7.2 (profiles/r04_notes.md) a replay is no faster than
+    # the eager launches once those carry no profiling events -- 100 frames: 0.754 ms eager, 0.798 ms replayed, 0.765 ms replayed
+    # with the copy-out; 500 frames: 2.546 / 2.524; 1000: 4.743 / 4.753 -- round 3's 0.836 -> 0.809 ms had compared a replay
+    # with eager launches that carried 11 events.  IRIS_VOCODER_GRAPH_FRAMES or the constructor argument turn it on.
+    GRAPH_MAX_FRAMES = 0
 
     def __init__(self, cfg: GeneratorConfig, state_dict: Mapping[str, object],
                  device: Optional[torch.device] = None, dtype: Optional[str] = None,

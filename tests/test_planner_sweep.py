@@ -2,7 +2,7 @@
 
 ``mrf_plan`` (csrc/mrf_conv_mfma_f32.h) picks, per MRF stage and per (batch, frames), among tile-serial launches
 (full / half tile height), fixed per-branch block ranges (all block slots / one block per CU), snake-ordered
-(tile, branch) jobs (full / half height), the 16 x 16-job kernel for short inputs, fused conv pairs and the summing
+(tile, branch) jobs (full / half height), 128-row tiles where they fill the chip, the 16 x 16-job kernel for short inputs, fused conv pairs and the summing
 forms.  Every one of them must compute ``HiFiGANModel.forward`` (reference src/iris/hifigan_pretrained.py:123-143): the
 shapes below are drawn across the switches (batch 1: 130 ... 999 frames; batches 2, 3, 5 at 200 ... 800 frames), a CPU
 test asserts -- from ``iris_hifigan_describe_plan``, which needs no device -- that the sweep really visits every plan
@@ -27,10 +27,10 @@ SWEEP_SHAPES = ([(1, t) for t in (130, 150, 190, 200, 240, 282, 350, 420, 480, 5
                 + [(2, 200), (2, 450), (2, 800), (3, 260), (3, 333), (3, 700), (5, 200), (5, 500), (5, 800)])
 BF16_SHAPES = [(1, 130), (1, 282), (1, 501), (1, 850), (2, 450), (3, 333), (5, 200)]
 
-PLAN_KINDS = {"small", "pair", "pair_sum", "serial_full", "serial_half", "sum_full", "sum_half", "ranges_all", "ranges_percu",
+PLAN_KINDS = {"small", "pair", "pair_sum", "serial_tall", "serial_full", "serial_half", "sum_full", "sum_half", "ranges_all", "ranges_percu",
               "snake_full", "snake_half", "dyn_tiles"}
 
-_MRF = re.compile(r"mrf_conv_mfma_f32_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\d+)>")
+_MRF = re.compile(r"mrf_conv_mfma_f32_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\d+)(?:, \w+)*>")
 
 
 def plan_kinds(cfg, B, T, cu_count=256):
@@ -40,10 +40,10 @@ def plan_kinds(cfg, B, T, cu_count=256):
     stage, L = -1, T
     for rec in plan["launches"]:
         name, grid = rec["kernel"], rec["grid"][0]
-        if name.startswith("conv_mfma_f32_kernel") and kinds.get("_pre"):
-            stage += 1
-            L *= cfg.upsample_rates[stage]
-        if name.startswith("conv_mfma_f32_kernel"):
+        if name.startswith(("conv_mfma_f32_kernel", "convt_mfma_f32_kernel")):      # conv_pre, then one upsampler per stage
+            if kinds.get("_pre"):
+                stage += 1
+                L *= cfg.upsample_rates[stage]
             kinds["_pre"] = 1
         if name.startswith("mrf_small_f32_kernel"):
             kinds["small"] += 1
@@ -57,7 +57,7 @@ def plan_kinds(cfg, B, T, cu_count=256):
                 continue
             WT, WC, MT = int(m.group(1)), int(m.group(2)), int(m.group(3))
             summing, mode = m.group(9) == "true", int(m.group(10))
-            height = "full" if MT == 2 else "half"
+            height = {1: "half", 2: "full", 4: "tall"}[MT]       # 32- / 64- / 128-row tiles
             if summing:
                 kinds["sum_" + height] += 1
             elif mode == 0:
