@@ -353,8 +353,8 @@ def test_launch_plan_of_the_wide_stages_follows_the_timing_model():
         for l in plan["launches"]:
             k = l["kernel"]
             if k.startswith("mrf_conv_mfma_f32_kernel"):
-                args = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")
-                out.append({"mode": int(args[-1]), "sum": args[-2] == "true", "mt": int(args[2]), "grid": l["grid"][0]})
+                args = k[k.index("<") + 1:k.rindex(">")].replace(" ", "").split(",")     # (10 arguments; 12 for the 128-row LEAN form)
+                out.append({"mode": int(args[9]), "sum": args[8] == "true", "mt": int(args[2]), "grid": l["grid"][0]})
             elif k.startswith("mrf_small"):
                 out.append({"mode": "small", "grid": l["grid"][0]})
         return out
@@ -362,8 +362,9 @@ def test_launch_plan_of_the_wide_stages_follows_the_timing_model():
     at700, at1000x4, at282, at100 = wide(700), wide(1000, 4), wide(282), wide(100)
     assert all(l["mode"] == 2 and l["grid"] == 512 for l in at700[:12])                 # 350 / 1400 tiles on 512 slots: jobs
     assert at700[0]["mt"] == 1 and at700[6]["mt"] == 2
-    assert all(l["mode"] == 0 and l["mt"] == 2 and l["grid"] in (500, 504, 512) for l in at1000x4[:12])   # whole rounds: tile-serial
-    assert at1000x4[5]["sum"] and at1000x4[11]["sum"]                                  # ... whose last step forms the mean itself
+    assert all(l["mode"] == 0 and l["grid"] in (500, 504, 512) for l in at1000x4[:12])                   # whole rounds: tile-serial,
+    assert all(l["mt"] == (2 if l["sum"] else 4) for l in at1000x4[:12])                                 # on 128-row tiles (round 4) ...
+    assert at1000x4[5]["sum"] and at1000x4[11]["sum"]                                  # ... whose last step (64 rows) forms the mean itself
     assert all(l["mode"] == 1 for l in at282[:12])                                      # fixed ranges
     assert at100[0]["mode"] == "small" and at100[6]["mode"] == 2
     for frames in (64, 100, 150, 282, 350, 500, 650, 700, 850, 1000, 1400, 2000):
@@ -382,6 +383,7 @@ def test_describe_plan_on_the_host():
     kernels = [l["kernel"] for l in p["launches"]]
     assert p["n_launches"] == len(kernels) and kernels[0].startswith("conv_mfma_f32_kernel") and "conv_post" in kernels[-1]
     assert sum(k.startswith("mrf_") for k in kernels) == p["n_launches"] - 6
+    assert sum(k.startswith("convt_mfma_f32_kernel") for k in kernels) == 4           # every upsampler as one GEMM launch (round 4)
     assert all(1 <= l["grid"][0] and l["block"] == 256 and l["lds_bytes"] <= 160 * 1024 for l in p["launches"])
     short = _native.describe_plan(cfg, 1, 100, _native.DTYPE_F32)
     assert any(k == "mrf_small_f32_kernel" for k in (l["kernel"] for l in short["launches"]))   # stage 0 on short inputs
