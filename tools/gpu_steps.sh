@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU call driver: TAG=<dir under gpurun_out> STEPS="tests bench launches" tools/r04_run.sh
+# One GPU call, several steps: TAG=<dir under gpurun_out> STEPS="tests bench launches" tools/gpu_steps.sh   (through gpurun, from the repo root)
 set -e
 OUT=gpurun_out/${TAG:-r04x}; mkdir -p $OUT
 for step in ${STEPS:-tests bench launches}; do
