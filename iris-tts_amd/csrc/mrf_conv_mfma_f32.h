@@ -57,9 +57,6 @@ namespace iris {
 #ifndef IRIS_MRF_TALL
 #define IRIS_MRF_TALL 1          // wide stages: tile-serial launches with enough tiles run 128-row tiles (MT = 4, LEAN registers); A/B builds: 0
 #endif
-#ifndef IRIS_MRF_DBUF
-#define IRIS_MRF_DBUF 0          // 1 = two LDS window buffers for the wide stages (see DBUF below): measured, no gain -- off
-#endif
 
 constexpr int kMrfSpanMax = 50;  // (ks-1)*dil of the widest supported conv: k=11, d=5
 
@@ -114,14 +111,10 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
     constexpr int T_BLK = WT * MT * 32;
     constexpr int NQ = ((T_BLK + kMrfSpanMax) * QPR + 255) / 256;  // staged 16-byte quads per thread
     constexpr int RPI = 256 / QPR;                                   // rows advanced per staged quad
-    // Wide stages (WT == 1: C >= 128, 64-channel chunks, phases of >= 24 groups): TWO window buffers.  The quads of phase
-    // p+1 are written into the other buffer during the LAST NQ groups of phase p's MFMA loop -- behind MFMAs, where a
-    // ds_write_b128 costs nothing -- so a phase ends with ONE barrier instead of barrier + LDS write + barrier (round 2's
-    // stamps: LDS write 2.6-3 % + second barrier 0.5 % of a wave's life at C = 256 / 128).  62-70 KB per block, two blocks per CU.
-    // Measured in round 3 (profiles/r03_notes.md): bit-identical, and no faster -- the CU's other block covers that time
-    // already -- so it is compiled out by default (IRIS_MRF_DBUF).
-    constexpr bool DBUF = (WT == 1) && (IRIS_MRF_DBUF != 0);
-    constexpr int BUF_ROWS = DBUF ? NQ * RPI : T_BLK + kMrfSpanMax;  // (DBUF: every staged quad has a row, written unconditionally)
+    // (Two window buffers with the next phase's quads written behind the last MFMA groups -- one barrier per phase instead of
+    //  barrier + LDS write + barrier -- were measured in round 3: bit-identical and no faster, the CU's other block covers that
+    //  time already; removed in round 4, profiles/r03_notes.md.)
+    constexpr int BUF_ROWS = T_BLK + kMrfSpanMax;
     constexpr int BUF_FLOATS = BUF_ROWS * S;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,7 +136,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
 #endif
     const unsigned tensor_bytes = (unsigned)L * (unsigned)C * 4u;
     // LEAN: [3][C_out] biases behind the window(s) and the next-tile word (launch_mrf_conv sizes the dynamic LDS for it)
-    float* const lds_bias = lds + (DBUF ? 2 : 1) * BUF_FLOATS + 4;
+    float* const lds_bias = lds + BUF_FLOATS + 4;
     if constexpr (LEAN) {
         const int q = a.C_out >> 2;                           // C_out % 4 == 0 (mrf_kernel_applicable)
         for (int i = tid; i < 3 * q; i += 256) {
@@ -207,13 +200,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
         // they would be real rows of the tensor, i.e. HBM reads that nobody uses
         st[i] = buf_load4(xr, r_lane + i * RPI < R ? vbase + (unsigned)i * row_stride : kOobOffset, 0);
     };
-    int cur = 0;                             // DBUF: the buffer the current phase reads
-    auto stage_write_one = [&](int i, float* dst) {   // DBUF: quad i of the next phase's window -> the other buffer
-        f32x4 v = st[i];                     // (rows past the window were requested out of range: zeros; their rows exist)
-        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-        *reinterpret_cast<f32x4*>(dst + i * RPI * S) = v;
-    };
     auto stage_write_all = [&](int R) {      // LeakyReLU on the way in (hifigan_pretrained.py:66,68)
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
@@ -222,7 +208,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                 f32x4 v = st[i];
                 v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
                 v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
-                *reinterpret_cast<f32x4*>(lds_wr + cur * BUF_FLOATS + i * RPI * S) = v;
+                *reinterpret_cast<f32x4*>(lds_wr + i * RPI * S) = v;
             }
     };
 
@@ -315,9 +301,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
             const unsigned wsoffn = last ? 0u : (unsigned)((chunk + 1) * GPC) * wbytes_group;
             const unsigned wvoffn = cross ? nj.wvoff : t.wvoff;
 
-            const float* const aptr_c = aptr + cur * BUF_FLOATS;
-            float* const lds_wr_n = lds_wr + (cur ^ 1) * BUF_FLOATS;
-            auto a_ptr = [&](int n) { return aptr_c + (n / GPC) * dilS + 8 * (n % GPC); };
+            auto a_ptr = [&](int n) { return aptr + (n / GPC) * dilS + 8 * (n % GPC); };
             auto b_load = [&](int n, unsigned voff_next) {   // group n of this phase, or group n-NG of the next one
                 if (n < NG)
                     return buf_load4(wr, t.wvoff, wsoff0 + (unsigned)(n / GPC) * tap_bytes + (unsigned)(n % GPC) * wbytes_group);
@@ -346,10 +330,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                         if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
                 }
                 if (!(ablate & 32)) bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
-                if constexpr (DBUF) {
-                    static_assert(!DBUF || NG >= 2 * NQ, "a phase must be long enough to request and write the next window");
-                    if (n >= NG - NQ) stage_write_one(n - (NG - NQ), lds_wr_n);
-                }
                 if constexpr (LEAN) {
                     // m-major: row tile m's four MFMAs, then its fragment of group n + 1 into the same registers
 #pragma unroll
@@ -498,25 +478,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
 #ifdef IRIS_MRF_STAMPS
             if (last) seg[7] += ts2 - ts1;
 #endif
-            if (DBUF && has_next) {
-                if (stored) {
-                    if constexpr (LEAN) {
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {      // (one register per statement: a 64-byte "v" operand is not valid in the host pass)
-                                if constexpr (SUM) asm volatile("" :: "v"(sumv[m][r])); else asm volatile("" :: "v"(acc[m][r]));
-                            }
-                    } else {
-#pragma unroll
-                        for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(outv[idx]));   // (keep-alive, see below)
-                    }
-                }
-                __syncthreads();          // every wave is done reading this window AND has written its share of the next one
-                cur ^= 1;
-                IRIS_STAMP(ts5);
-                IRIS_SEG(2, ts2, ts5);
-            } else if (has_next) {
+            if (has_next) {
                 __syncthreads();          // every wave is done reading this chunk's window
                 IRIS_STAMP(ts3);
                 stage_write_all(Rn);
@@ -569,7 +531,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                        __builtin_amdgcn_readfirstlane(a.p[PN].ks), __builtin_amdgcn_readfirstlane(a.p[PN].dil),
                        __builtin_amdgcn_readfirstlane(a.p[PN].pad_left)};
     };
-    unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + (DBUF ? 2 : 1) * BUF_FLOATS);   // LDS word: a drawn tile / job index
+    unsigned* const next_slot = reinterpret_cast<unsigned*>(lds + BUF_FLOATS);   // LDS word: a drawn tile / job index
     if constexpr (ZPAR == 0) {
         // equal-cost blocks: every block runs all three branches of its tiles, heaviest first:
         // p[2] (KC taps), p[1] (KB), p[0] (KA); persistent over tiles
@@ -930,10 +892,6 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     const bool lean = tall;
     size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;         // + next-tile word
     if (lean) lds_bytes += (size_t)3 * a.C_out * sizeof(float);                                   // + the bias table of the LEAN form
-    if (t.WT == 1 && IRIS_MRF_DBUF) {    // two window buffers of NQ * RPI rows (see the kernel)
-        const int qpr = t.CIC / 4, nq = ((T_BLK + kMrfSpanMax) * qpr + 255) / 256, rpi = 256 / qpr;
-        lds_bytes = (size_t)2 * nq * rpi * (t.CIC + 4) * sizeof(float) + 16;
-    }
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
     const int dyn_env = IRIS_DIAG_ENV("IRIS_HIFIGAN_DYNTILES", 1);
     if (!dyn_env || pl.zpar || plx.n_tiles < 4 * plx.grid) a.dyn_counter = nullptr;
@@ -951,15 +909,20 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
 #define IRIS_MRF_LAUNCH_TALL_1(WC_, CIC_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 4, CIC_, 2, 3, 7, 11, false, 0, 2, true>)
 #define IRIS_MRF_LAUNCH_TALL_2(WC_, CIC_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_TALL_4(WC_, CIC_) return hipErrorInvalidValue
+    // (snake-ordered jobs need two or more C_in chunks -- mrf_plan's zdyn_ok: the wide tile only; the narrow tiles are not instantiated)
+#define IRIS_MRF_LAUNCH_SNAKE(WT_, WC_, MT_, CIC_, D_) IRIS_MRF_LAUNCH_SNAKE_##WT_(WC_, MT_, CIC_, D_)
+#define IRIS_MRF_LAUNCH_SNAKE_1(WC_, MT_, CIC_, D_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, MT_, CIC_, D_, 3, 7, 11, false, 2>)
+#define IRIS_MRF_LAUNCH_SNAKE_2(WC_, MT_, CIC_, D_) return hipErrorInvalidValue
+#define IRIS_MRF_LAUNCH_SNAKE_4(WC_, MT_, CIC_, D_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_, D1_, D2_)                                                       \
     do {                                                                                          \
         if (tall) IRIS_MRF_LAUNCH_TALL(WT_, WC_, CIC_);                                            \
         else if (pl.MT == 2) {                                                                    \
-            if (pl.zdyn) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 2>);   \
+            if (pl.zdyn) IRIS_MRF_LAUNCH_SNAKE(WT_, WC_, 2, CIC_, D2_);                           \
             else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 11, 7, 3, true, 0>);   \
             else         IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 3, 7, 11, false, 0>);  \
         } else if (a.sum_y)  IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 11, 7, 3, true, 0>);   \
-        else if (pl.zdyn)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 2>);   \
+        else if (pl.zdyn)    IRIS_MRF_LAUNCH_SNAKE(WT_, WC_, 1, CIC_, D1_);                       \
         else if (pl.zpar)    IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 1>);   \
         else                 IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 1, CIC_, D1_, 3, 7, 11, false, 0>);  \
     } while (0)
@@ -1024,6 +987,10 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     }
 #endif
 #undef IRIS_MRF_LAUNCH_DB
+#undef IRIS_MRF_LAUNCH_SNAKE
+#undef IRIS_MRF_LAUNCH_SNAKE_1
+#undef IRIS_MRF_LAUNCH_SNAKE_2
+#undef IRIS_MRF_LAUNCH_SNAKE_4
 #undef IRIS_MRF_LAUNCH_TALL
 #undef IRIS_MRF_LAUNCH_TALL_1
 #undef IRIS_MRF_LAUNCH_TALL_2
