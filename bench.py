@@ -397,6 +397,15 @@ def rank_main(args):
     from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
     from iris.distributed import gather_waveforms, shard_range
 
+    # ONE JSON line on stdout, nothing else: libraries that chat on fd 1 (RCCL prints a five-line version banner at init, gloo its
+    # connection lines) are sent to stderr for the life of the rank; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -725,7 +734,7 @@ def rank_main(args):
             out["other_modes"] = modes
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
