@@ -885,7 +885,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
         const long long slots = 2LL * mrf_cu_count();
         long long g4 = n4 < slots ? n4 : slots; if (g4 < 1) g4 = 1;
         const long long r4 = (n4 + g4 - 1) / g4; g4 = (n4 + r4 - 1) / r4;
-        if (g4 >= pl.grid - 16) { tall = true; plt.MT = 4; plt.n_tiles = n4; plt.grid = g4; }
+        if (g4 >= pl.grid) { tall = true; plt.MT = 4; plt.n_tiles = n4; plt.grid = g4; }
     }
     const MrfPlan& plx = plt;
     const int T_BLK = t.WT * plx.MT * 32;
