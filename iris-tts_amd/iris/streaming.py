@@ -138,3 +138,87 @@ class StreamingVocoder:
             return torch.cat(parts, dim=1)
         import numpy as np
         return np.concatenate(parts, axis=1)
+
+
+class StreamingSession:
+    """Incremental chunked vocoding: the mel of ONE utterance arrives piece by piece (``push``), audio leaves chunk by chunk
+    as soon as its right-hand context exists, and ``flush`` ends the utterance.  The concatenation of everything returned
+    equals the one-shot forward of the concatenated mel: chunk ``[s, s + chunk)`` is vocoded from the window
+    ``[max(0, s - halo), min(T, s + chunk + halo))`` exactly as ``plan_chunks`` would cut it once the length T is known, and a
+    sample depends on the mel within the halo only (``receptive_field_frames``).
+
+    The reference has no streaming (``TTSPipeline`` is a stub, src/iris/model.py:17-27); BASELINE.json configs[4] asks for
+    256-frame chunks.  ``StreamingVocoder`` covers a mel that is already complete; this class is for a producer (an
+    acoustic model emitting frames) that is still running.  Latency: a chunk is emitted ``halo`` frames (13 for V1 = 0.15 s
+    of audio) after its last frame has arrived.  At most ``chunk + 2 * halo`` frames are buffered."""
+
+    def __init__(self, forward: Callable, hop_length: Optional[int] = None, chunk_frames: int = 256,
+                 halo_frames: Optional[int] = None, config=None):
+        sv = StreamingVocoder(forward, hop_length=hop_length, chunk_frames=chunk_frames, halo_frames=halo_frames, config=config)
+        self.forward, self.hop_length = sv.forward, sv.hop_length
+        self.chunk_frames, self.halo_frames = sv.chunk_frames, sv.halo_frames
+        self._pieces: list = []       # buffered mel pieces [B, n_mels, t]; together they cover frames [self._base, self._total)
+        self._base = 0                # absolute index of the first buffered frame
+        self._total = 0               # frames received so far
+        self._next = 0                # first frame not yet emitted
+        self._closed = False
+
+    @property
+    def frames_received(self) -> int:
+        return self._total
+
+    @property
+    def frames_emitted(self) -> int:
+        return self._next
+
+    def _cat(self):
+        if len(self._pieces) > 1:
+            first = self._pieces[0]
+            if hasattr(first, "detach"):
+                import torch
+                self._pieces = [torch.cat(self._pieces, dim=2)]
+            else:
+                import numpy as np
+                self._pieces = [np.concatenate(self._pieces, axis=2)]
+        return self._pieces[0]
+
+    def _emit_ready(self, final: bool) -> List:
+        out = []
+        while self._next < self._total:
+            stop = min(self._next + self.chunk_frames, self._total)
+            whole = stop - self._next == self.chunk_frames
+            if not final and (not whole or self._total < stop + self.halo_frames):
+                break                                             # the chunk, or its right-hand context, is still incomplete
+            win_start = max(0, self._next - self.halo_frames)
+            win_stop = min(self._total, stop + self.halo_frames)
+            buf = self._cat()
+            wav = self.forward(buf[:, :, win_start - self._base:win_stop - self._base])
+            out.append(wav[:, (self._next - win_start) * self.hop_length:(stop - win_start) * self.hop_length])
+            self._next = stop
+            keep_from = max(0, self._next - self.halo_frames)    # the next chunk's left-hand context
+            if keep_from > self._base:
+                self._pieces = [buf[:, :, keep_from - self._base:]]
+                self._base = keep_from
+        return out
+
+    def push(self, mel_piece) -> List:
+        """Appends ``mel_piece [B, n_mels, t]`` (t >= 0) and returns the waveform chunks ``[B, hop * chunk]`` that became
+        computable, in order (possibly none)."""
+        if self._closed:
+            raise RuntimeError("the session was flushed: start a new one for the next utterance")
+        if mel_piece.ndim != 3:
+            raise ValueError(f"expected mel [B, n_mels, t], got shape {tuple(mel_piece.shape)}")
+        if self._pieces and tuple(mel_piece.shape[:2]) != tuple(self._pieces[0].shape[:2]):
+            raise ValueError("every piece of an utterance must have the same batch size and mel bins")
+        if mel_piece.shape[2] > 0:
+            self._pieces.append(mel_piece)
+            self._total += int(mel_piece.shape[2])
+        return self._emit_ready(final=False)
+
+    def flush(self) -> List:
+        """Ends the utterance: returns the chunks that were waiting for context (the last one may be shorter than
+        ``chunk_frames``); the right edge of the last window is the true end of the mel, as in the one-shot forward."""
+        out = self._emit_ready(final=True)
+        self._closed = True
+        self._pieces = []
+        return out

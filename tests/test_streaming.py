@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from iris.streaming import RECEPTIVE_FIELD_FRAMES, StreamingVocoder, plan_chunks
+from iris.streaming import RECEPTIVE_FIELD_FRAMES, StreamingSession, StreamingVocoder, plan_chunks
 from iris._weights import GeneratorConfig, seeded_mel, seeded_state_dict
 from oracle import hifigan_oracle as orc
 
@@ -103,4 +103,82 @@ def test_grouped_streaming_on_gpu_is_exact():
     sd = seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0)
     want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel.cpu().numpy()).numpy()[0, 0]
     assert np.abs(grouped[0].cpu().numpy() - want).max() <= 1e-4
+    eng.close()
+
+
+def test_incremental_session_equals_complete_mel_streaming():
+    """StreamingSession (mel arriving piece by piece) cuts the same windows as plan_chunks does once the length is known:
+    same chunks, same samples, whatever the piece sizes; a chunk leaves `halo` frames after its last frame arrived."""
+    calls = []
+
+    def fwd(m):                                    # +-13-frame dependence like the generator, hop 4
+        calls.append(tuple(m.shape))
+        k = np.ones(27) / 27.0
+        y = np.stack([np.convolve(m[b].sum(0), k, mode="same") for b in range(m.shape[0])])
+        return np.repeat(y, 4, axis=1)
+
+    rng = np.random.default_rng(5)
+    for T in (0, 1, 13, 255, 256, 257, 269, 270, 700, 1024):
+        mel = rng.standard_normal((2, 5, T)).astype(np.float32)
+        want = list(StreamingVocoder(fwd, hop_length=4, chunk_frames=256).stream(mel))
+        want_calls = calls[:]
+        calls.clear()
+        ses = StreamingSession(fwd, hop_length=4, chunk_frames=256)
+        got, pos = [], 0
+        while pos < T:
+            n = int(rng.integers(0, 90))
+            before = len(got)
+            got += ses.push(mel[:, :, pos:pos + n])
+            pos = min(T, pos + n)
+            assert ses.frames_received == pos
+            if len(got) > before:                  # emitted exactly when the right-hand context became complete
+                assert ses.frames_emitted + RECEPTIVE_FIELD_FRAMES <= pos
+            assert pos - ses.frames_emitted < 256 + RECEPTIVE_FIELD_FRAMES + 90
+        got += ses.flush()
+        assert calls == want_calls, T              # the very same windows
+        calls.clear()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        with pytest.raises(RuntimeError):
+            ses.push(mel[:, :, :1])
+    with pytest.raises(ValueError):
+        StreamingSession(fwd, halo_frames=RECEPTIVE_FIELD_FRAMES - 1)
+
+
+def test_incremental_session_on_the_oracle():
+    cfg = GeneratorConfig()
+    sd = seeded_state_dict(cfg, seed=2025, gain=1.18, post_gain=20.0)
+    folded = orc.to_torch_folded(sd)
+    mel = seeded_mel(1006, 1, 61, log_mel=True)
+    fwd = lambda m: orc.generator_forward_torch(folded, np.ascontiguousarray(m)).numpy()[:, 0, :]
+    full = fwd(mel)
+    ses = StreamingSession(fwd, chunk_frames=16, config=cfg)
+    parts = []
+    for s in range(0, 61, 7):
+        parts += ses.push(mel[:, :, s:s + 7])
+    parts += ses.flush()
+    got = np.concatenate(parts, axis=1)
+    assert got.shape == full.shape and np.abs(got - full).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_incremental_session_on_gpu_is_exact():
+    from iris._engine import GeneratorEngine
+    cfg = GeneratorConfig()
+    dev = torch.device("cuda", 0)
+    sd = seeded_state_dict(cfg, seed=3, gain=1.1, post_gain=10.0)
+    eng = GeneratorEngine(cfg, sd, dev)
+    mel = torch.from_numpy(seeded_mel(10, 2, 900, log_mel=True)).to(dev)
+    one_shot = eng.forward(mel).clone()
+    ses = StreamingSession(lambda m: eng.forward(m.contiguous()).clone(), config=cfg)
+    parts = []
+    for s in range(0, 900, 100):                   # an acoustic model emitting 100 frames at a time
+        parts += ses.push(mel[:, :, s:s + 100])
+    parts += ses.flush()
+    assert [p.shape[1] for p in parts] == [65536, 65536, 65536, 132 * 256]
+    got = torch.cat(parts, dim=1)
+    assert torch.equal(got, one_shot)
+    want = orc.generator_forward_torch(orc.to_torch_folded(sd), mel[1:2].cpu().numpy()).numpy()[0, 0]
+    assert np.abs(got[1].cpu().numpy() - want).max() <= 1e-4
     eng.close()
