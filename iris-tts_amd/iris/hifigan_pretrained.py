@@ -199,6 +199,10 @@ class HiFiGANModel(nn.Module):
         return tuple(self._version_of(t) for t in tensors)
 
     def engine(self) -> GeneratorEngine:
+        if any(isinstance(m, _WeightNormedConv) and not m.initialised for m in self.modules()):
+            # a deferred construction that nobody finished: every layer nothing was loaded into gets its default draw
+            self.finish_init([f"{n}.weight_v" for n, m in self.named_modules()
+                              if isinstance(m, _WeightNormedConv) and not m.initialised])
         if self._engine is not None and self._parameter_versions() != self.__dict__.get("_packed_versions"):
             logger.info("HiFiGAN parameters changed since they were packed for the GPU: repacking")
             self._drop_engine()
