@@ -1,6 +1,6 @@
 #!/bin/bash
 # Release-vs-release A/B on ONE box, interleaved: per-shape median step time of the wide fp32 MRF launches (tools/plan_sweep.py)
-# for each library build.  usage: LIBS="release lean3" SHAPES="1:1000 32:500" ROUNDS=2 OUT=gpurun_out/x tools/ab_sweep.sh
+# for each library build.  usage: LIBS="release notall" SHAPES="1:1000 32:500" ROUNDS=2 OUT=gpurun_out/x tools/ab_sweep.sh
 # ("release" = csrc/libiris_hifigan.so, any other name = csrc/libiris_hifigan_<name>.so from `make relvariant NAME=<name>`)
 set -e
 OUT=${OUT:-gpurun_out/ab}; mkdir -p $OUT
