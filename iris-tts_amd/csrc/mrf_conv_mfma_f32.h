@@ -54,9 +54,6 @@ namespace iris {
 #ifndef IRIS_MRF_MINWAVES
 #define IRIS_MRF_MINWAVES 2      // waves per SIMD the register allocator must leave room for
 #endif
-#ifndef IRIS_MRF_SPREAD
-#define IRIS_MRF_SPREAD 0        // wide stages, 64-row tiles: stores of a branch spread over the next phase's groups (SPR); A/B builds: 1
-#endif
 #ifndef IRIS_MRF_TALL
 #define IRIS_MRF_TALL 1          // wide stages: tile-serial launches with enough tiles run 128-row tiles (MT = 4, LEAN registers); A/B builds: 0
 #endif
@@ -104,15 +101,10 @@ __device__ __forceinline__ T* uniform_ptr_mrf(T* p) {     // a block-uniform poi
 //     then of row tile 1), and row tile m's fragment of the NEXT group is requested as soon as its four MFMAs have issued
 //     (256 cycles ahead of its use).  v_mfma_f32_32x32x2_f32 chains on one accumulator back to back (SrcC forwarding).
 // Every output element is the same fmaf chain in the same order as in the MINW = 2 form: bit-identical.
-// SPR (with LEAN): the stores of a branch are not issued as a burst behind its last MFMA but one per group in the phase that FOLLOWS
-// (groups behind that phase's staging / residual requests), from a copy of the results that lives until then.  A burst of 8
-// buffer_store_dwordx4 per wave holds up the CU's vector-memory path for everybody (tools/mrf_skeleton.hip: 2-4 % of the matrix
-// pipe's time, most of it back when the stores are spread); same arithmetic, same bits.
-template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR, int MINW = IRIS_MRF_MINWAVES, bool LEANP = (MINW >= 3), bool SPRP = false>
+template <int WT, int WC, int MT, int CIC, int DB, int KA, int KB, int KC, bool SUM, int ZPAR, int MINW = IRIS_MRF_MINWAVES, bool LEANP = (MINW >= 3)>
 __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const ConvLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool LEAN = LEANP;
-    constexpr bool SPR = SPRP && LEANP;
     constexpr int S = CIC + 4;
     constexpr int QPR = CIC / 4;
     constexpr int GPC = CIC / 8;
@@ -242,10 +234,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
     f32x16 sumv[MT];      // SUM kernels only: running MRF sum of the branch outputs of this tile
     f32x4 bw[DB + 1];     // ring of weight fragments; groups 0..DB-1 of a phase are requested by the
                           // phase before it (or by the prologue)
-    // SPR: the finished branch's results wait here for the next phase's store slots; pend_voff is out of range when nothing waits
-    f32x4 pend[SPR ? MT * 4 : 1];
-    const float* pend_base = a.p[0].y;
-    unsigned pend_voff = kOobOffset;
 
     // What follows a branch's last chunk: the next branch of the same tile, a branch of the block's next tile or job -- or
     // nothing (valid == false) at the very end.
@@ -330,7 +318,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
             // one basic block and sched_group_barrier can slot ONE request behind each MFMA: every
             // request then issues in the 64-cycle shadow of an MFMA instead of piling up at the
             // group boundary.
-            const __amdgpu_buffer_rsrc_t pend_rs = make_rsrc(pend_base, tensor_bytes);
             const unsigned vbn_eff = has_next ? vbn : kOobOffset;
             const unsigned res_voff = last ? t.ovoff4 : kOobOffset;
             const unsigned wvoffn_eff = has_next ? wvoffn : kOobOffset;
@@ -343,13 +330,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                         if (n * RPG + j < NRES) res_load(n * RPG + j, res_voff);
                 }
                 if (!(ablate & 32)) bw[(n + DB) % (DB + 1)] = b_load(n + DB, wvoffn_eff);
-                // SPR: store slot of this group (the previous branch's piece n - ST0), behind every read request of the phase
-                constexpr int ST0 = NQ > (NRES + RPG - 1) / RPG ? NQ : (NRES + RPG - 1) / RPG;
-                const bool st_here = SPR && n >= ST0 && n - ST0 < MT * 4;
-                if constexpr (SPR) {
-                    if (st_here)
-                        buf_store4(pend[n - ST0], pend_rs, pend_voff, (unsigned)(((n - ST0) / 4) * 32 * C + 8 * ((n - ST0) % 4)) * 4u);
-                }
                 if constexpr (LEAN) {
                     // m-major: row tile m's four MFMAs, then its fragment of group n + 1 into the same registers
 #pragma unroll
@@ -361,14 +341,13 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                     }
                     // schedule: per row tile 4 MFMAs with one memory request behind each of the first ones, then the DS read
                     const int n_vm = 1 + (n < NQ ? 1 : 0) + ((n * RPG < NRES) ? ((NRES - n * RPG) < RPG ? (NRES - n * RPG) : RPG) : 0);
-                    int vm_left = n_vm, st_left = st_here ? 1 : 0;
+                    int vm_left = n_vm;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             if (vm_left > 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); --vm_left; }
-                            else if (st_left > 0) { __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); --st_left; }
                         }
                         if (n + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
@@ -401,14 +380,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
             }
 #pragma unroll
             for (int i = NG; i < NQ; ++i) stage_load_one(i, xrn, vbn_eff, Rn);
-            if constexpr (SPR) {
-                constexpr int ST0 = NQ > (NRES + RPG - 1) / RPG ? NQ : (NRES + RPG - 1) / RPG;
-                // (a phase too short for all the slots -- not the case for 64-channel chunks -- issues the rest here)
-#pragma unroll
-                for (int idx = NG > ST0 ? NG - ST0 : 0; idx < MT * 4; ++idx)
-                    buf_store4(pend[idx], pend_rs, pend_voff, (unsigned)((idx / 4) * 32 * C + 8 * (idx % 4)) * 4u);
-                pend_voff = kOobOffset;
-            }
             IRIS_STAMP(ts1);
             IRIS_SEG(0, ts0, ts1);
             // the next phase expects its groups 0..DB-1 in ring slots 0..DB-1: they were loaded into
@@ -465,26 +436,7 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                         }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (SPR && (!SUM || PI == 0)) {
-                    // a copy that outlives the accumulators' zero-init; stored by the next phase, or right here when there is none
-#pragma unroll
-                    for (int idx = 0; idx < MT * 4; ++idx) {
-                        const f32x16& src = SUM ? sumv[idx / 4] : acc[idx / 4];
-                        const int g = idx % 4;
-                        pend[idx] = f32x4{src[4 * g + 0], src[4 * g + 1], src[4 * g + 2], src[4 * g + 3]};
-                    }
-                    pend_base = (SUM ? a.sum_y : p.y) + t.batch_off;
-                    if (has_next) {
-                        pend_voff = (ablate & 4) ? kOobOffset : t.ovoff4;
-                    } else {
-                        const __amdgpu_buffer_rsrc_t yo = make_rsrc(pend_base, tensor_bytes);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int idx = 0; idx < MT * 4; ++idx)
-                            buf_store4(pend[idx], yo, t.ovoff4, (unsigned)((idx / 4) * 32 * C + 8 * (idx % 4)) * 4u);
-                        asm volatile("s_nop 1");
-                    }
-                } else if constexpr (LEAN && (!SUM || PI == 0)) {
+                if constexpr (LEAN && (!SUM || PI == 0)) {
                     // straight from the accumulators / the running sum: these registers are next written by the zero-init of
                     // the following branch, i.e. behind the LDS write and both barriers below (keep-alive there)
                     const __amdgpu_buffer_rsrc_t yo = SUM ? make_rsrc(a.sum_y + t.batch_off, tensor_bytes) : yr;
@@ -547,11 +499,6 @@ __global__ void __launch_bounds__(256, MINW) mrf_conv_mfma_f32_kernel(const Conv
                     }
                 }
                 __syncthreads();
-                if constexpr (SPR) {
-                    // the store-data registers stay allocated (and unwritten) from the copy to the end of the phase that stores them
-#pragma unroll
-                    for (int idx = 0; idx < MT * 4; ++idx) asm volatile("" :: "v"(pend[idx]));
-                }
                 IRIS_STAMP(ts5);
                 IRIS_SEG(2, ts2, ts3); IRIS_SEG(3, ts3, ts4); IRIS_SEG(4, ts4, ts5);
             }
@@ -942,9 +889,7 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     }
     const MrfPlan& plx = plt;
     const int T_BLK = t.WT * plx.MT * 32;
-    // 64-row wide tiles in the spread-stores form (LEAN registers + SPR): see the kernel's SPR note
-    const bool spread = IRIS_MRF_SPREAD && !tall && t.WT == 1 && pl.MT == 2;
-    const bool lean = tall || spread;
+    const bool lean = tall;
     size_t lds_bytes = (size_t)(T_BLK + kMrfSpanMax) * (t.CIC + 4) * sizeof(float) + 16;         // + next-tile word
     if (lean) lds_bytes += (size_t)3 * a.C_out * sizeof(float);                                   // + the bias table of the LEAN form
     // the counter only pays when a block walks several tiles (each fetch delays one wave by an atomic round trip)
@@ -967,26 +912,11 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
     // (snake-ordered jobs need two or more C_in chunks -- mrf_plan's zdyn_ok: the wide tile only; the narrow tiles are not instantiated)
 #define IRIS_MRF_LAUNCH_SNAKE(WT_, WC_, MT_, CIC_, D_) IRIS_MRF_LAUNCH_SNAKE_##WT_(WC_, MT_, CIC_, D_)
 #define IRIS_MRF_LAUNCH_SNAKE_1(WC_, MT_, CIC_, D_) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, MT_, CIC_, D_, 3, 7, 11, false, 2>)
-    // (the spread-stores form: wide tile, 64 rows)
-#define IRIS_MRF_LAUNCH_SPREAD(WT_, WC_, CIC_, D_) IRIS_MRF_LAUNCH_SPREAD_##WT_(WC_, CIC_, D_)
-#if IRIS_MRF_SPREAD
-#define IRIS_MRF_LAUNCH_SPREAD_1(WC_, CIC_, D_)                                                                                      \
-    do {                                                                                                                             \
-        if (pl.zdyn)      IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 2, CIC_, D_, 3, 7, 11, false, 2, 2, true, true>);       \
-        else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 2, CIC_, D_, 11, 7, 3, true, 0, 2, true, true>);        \
-        else              IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<1, WC_, 2, CIC_, D_, 3, 7, 11, false, 0, 2, true, true>);       \
-    } while (0)
-#else
-#define IRIS_MRF_LAUNCH_SPREAD_1(WC_, CIC_, D_) return hipErrorInvalidValue
-#endif
-#define IRIS_MRF_LAUNCH_SPREAD_2(WC_, CIC_, D_) return hipErrorInvalidValue
-#define IRIS_MRF_LAUNCH_SPREAD_4(WC_, CIC_, D_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_SNAKE_2(WC_, MT_, CIC_, D_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_SNAKE_4(WC_, MT_, CIC_, D_) return hipErrorInvalidValue
 #define IRIS_MRF_LAUNCH_DB(WT_, WC_, CIC_, D1_, D2_)                                                       \
     do {                                                                                          \
         if (tall) IRIS_MRF_LAUNCH_TALL(WT_, WC_, CIC_);                                            \
-        else if (spread) IRIS_MRF_LAUNCH_SPREAD(WT_, WC_, CIC_, D2_);                              \
         else if (pl.MT == 2) {                                                                    \
             if (pl.zdyn) IRIS_MRF_LAUNCH_SNAKE(WT_, WC_, 2, CIC_, D2_);                           \
             else if (a.sum_y) IRIS_MRF_LAUNCH_K(mrf_conv_mfma_f32_kernel<WT_, WC_, 2, CIC_, D2_, 11, 7, 3, true, 0>);   \
@@ -1062,10 +992,6 @@ inline hipError_t launch_mrf_conv(ConvLaunch& a, int nz, hipStream_t stream, int
 #undef IRIS_MRF_LAUNCH_SNAKE_2
 #undef IRIS_MRF_LAUNCH_SNAKE_4
 #undef IRIS_MRF_LAUNCH_TALL
-#undef IRIS_MRF_LAUNCH_SPREAD
-#undef IRIS_MRF_LAUNCH_SPREAD_1
-#undef IRIS_MRF_LAUNCH_SPREAD_2
-#undef IRIS_MRF_LAUNCH_SPREAD_4
 #undef IRIS_MRF_LAUNCH_TALL_1
 #undef IRIS_MRF_LAUNCH_TALL_2
 #undef IRIS_MRF_LAUNCH_TALL_4
