@@ -11,6 +11,8 @@
 //   AHEAD (a candidate) the weight fragments of groups DB .. DB+7 of the phase BEHIND an epilogue are requested before that epilogue's
 //      stores, into the residual registers (free once the residual is added): the first request behind the stores is then waited for
 //      12 groups later instead of 4 (vmcnt counts loads and stores together, in issue order)
+//   LATE  (a candidate) the stores leave from a copy BEHIND the phase transition (barrier, LDS write, barrier) instead of in front of it:
+//      the other waves of the block then do not wait at the barrier for the slowest wave's stores to issue
 //   D  (a candidate, not what the kernel does) two LDS images: the staged quad of group n is written to the OTHER image in group n + 6,
 //      behind an MFMA like every other request -- no write burst between the phases, one barrier per phase instead of two
 // A block = 4 waves = 64 rows x 128 channels like the kernel (C = 128: two chunks per branch, six phases per tile), persistent over
@@ -22,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-enum { W = 1, P = 2, S = 4, E = 8, V = 16, D = 32, NOST = 64, NORES = 128, SPREAD = 256, FULL = 512, RFULL = 1024, LAT = 2048, UNI = 4096, AHEAD = 8192 };
+enum { W = 1, P = 2, S = 4, E = 8, V = 16, D = 32, NOST = 64, NORES = 128, SPREAD = 256, FULL = 512, RFULL = 1024, LAT = 2048, UNI = 4096, AHEAD = 8192, LATE = 16384 };
 #ifndef SKEL_DB
 #define SKEL_DB 4
 #endif
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) skeleton(const float* w, const float* 
                 }
                 if constexpr (F & NOST) {
                     keep += acc[0][0] + acc[1][5] + acc[0][9] + acc[1][14];
-                } else if constexpr (F & SPREAD) {
+                } else if constexpr ((F & SPREAD) || (F & LATE)) {
 #pragma unroll
                     for (int idx = 0; idx < 8; ++idx) {
                         const f32x16& src = acc[idx / 4];
@@ -226,6 +228,15 @@ __global__ void __launch_bounds__(256, 2) skeleton(const float* w, const float* 
                         for (int q = 0; q < 16; ++q) asm volatile("" :: "v"(acc[m][q]));
                 }
                 __syncthreads();
+                if constexpr (F & LATE) {
+                    if (out_pending) {
+#pragma unroll
+                        for (int idx = 0; idx < 8; ++idx)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[idx]), yr, (int)out_voff, (int)((idx / 4) * 32 * 512 + 32 * (idx % 4)), 0);
+                        asm volatile("s_nop 1");
+                        out_pending = false;
+                    }
+                }
             }
         }
     }
@@ -299,6 +310,7 @@ int main(int argc, char** argv) {
         run<W | P | S | E | V | SPREAD | UNI>("W P S E V, stores spread evenly over the whole next phase", blocks, T, w, x, res, y, sink);
         run<W | P | S | E | V | AHEAD>("W P S E V, 8 weight fragments requested ahead of the stores", blocks, T, w, x, res, y, sink);
         run<W | P | S | E | V | AHEAD | SPREAD>("W P S E V, fragments ahead AND stores spread", blocks, T, w, x, res, y, sink);
+        run<W | P | S | E | V | LATE>("W P S E V, stores behind the phase transition (from a copy)", blocks, T, w, x, res, y, sink);
         run<W | P | S | E | V | FULL>("W P S E V, stores as 8 rows x 128 B per instruction", blocks, T, w, x, res, y, sink);
         run<W | P | S | E | V | FULL | RFULL>("W P S E V, stores AND residual loads as 8 rows x 128 B", blocks, T, w, x, res, y, sink);
         run<W | P | S | E | V | LAT>("W P S E V + a vmcnt(0) right behind the stores, timed", blocks, T, w, x, res, y, sink);
