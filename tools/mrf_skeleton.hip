@@ -8,6 +8,11 @@
 //   S  staging loads: in the first 8 groups of a phase one 16-byte load per thread from a real 32 MB tensor (written beforehand)
 //   E  epilogue behind every second phase: 8 residual loads requested in its first 8 groups, bias + residual adds, 8 dwordx4 stores
 //   V  the three branch lengths (88 / 56 / 24 groups per phase) instead of 56 everywhere
+//   NOST / NORES  the epilogue without its stores / without its residual loads (what each costs)
+//   SPREAD [UNI]  (a candidate) the stores leave one per group in groups 8 .. 15 of the NEXT phase (UNI: evenly over the whole phase), from a copy
+//   FULL / RFULL  stores / residual loads addressed as 8 rows x 128 contiguous bytes per instruction instead of 32 rows x 2 x 16 bytes
+//   LAT  an s_waitcnt vmcnt(0) right behind the store burst, timed with s_memtime: how long the stores take to be acknowledged
+//   (-DSKEL_DB=8: weight ring of 8; -DSKEL_STORE_AUX=1 / 2 / 17: sc0 / nt / sc0 sc1 stores; every run prints the clock the chip held)
 //   AHEAD (a candidate) the weight fragments of groups DB .. DB+7 of the phase BEHIND an epilogue are requested before that epilogue's
 //      stores, into the residual registers (free once the residual is added): the first request behind the stores is then waited for
 //      12 groups later instead of 4 (vmcnt counts loads and stores together, in issue order)
