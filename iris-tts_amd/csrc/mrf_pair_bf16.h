@@ -7,8 +7,9 @@
 // xt = bf16(acc + bias), LeakyReLU(xt) -> bf16, y = bf16(acc + bias + x).  The numbers are bit for bit those of the
 // two separate launches of conv_mfma_bf16_kernel (same MFMA order, same roundings) -- what changes is the traffic:
 // xt never leaves the CU.  Unfused, a pair costs five tensor passes over HBM (conv1: read x, write xt; conv2: read
-// xt, read x, write y); fused it costs two (read x window, write y) plus the residual re-read, which the L2 / MALL
-// serves because the same block fetched those rows a few microseconds earlier.  At bf16 the C = 32 / 64 stages are
+// xt, read x, write y); fused it costs two (read x window, write y): the residual pieces of the block's rows are requested
+// right behind the window's LDS write, while the window load's lines are still in the L2 (round 4; requested in the epilogue,
+// tens of microseconds later, they came from HBM a second time: 2.0x the compulsory reads).  At bf16 the C = 32 / 64 stages are
 // HBM-bound (86 / 172 FLOP/B against a machine balance of ~312), so bytes are what their time is made of.
 //
 // Work split.  A 256-thread block owns M = WT*MT*32 consecutive rows of xt and ALL C channels (WC*NT*32 == C), for
@@ -19,7 +20,7 @@
 //      into the SAME LDS region (the x window is dead by then)
 //   4. conv2 on the matrix cores from that window: rows [o0, o0 + M); only the first T_OUT = M - (k-1) are valid
 //      (the last k-1 would need xt rows this block does not have) -- blocks advance by T_OUT rows
-//   5. epilogue as in conv_mfma_bf16.h (per-wave LDS transpose, 16-byte residual loads and stores).
+//   5. epilogue as in conv_mfma_bf16.h (per-wave LDS transpose, 16-byte stores; the residual pieces are in registers since step 1).
 // The (k-1)/M rows of conv2 that are computed and thrown away are the price of keeping xt on chip: 0.5-2.6 % at
 // M = 384, 1-5 % at M = 192-256.
 //
@@ -29,6 +30,9 @@
 #pragma once
 #include <stdio.h>
 #include "conv_mfma_bf16.h"
+#ifndef IRIS_B16_RES_EARLY
+#define IRIS_B16_RES_EARLY 1     // fused pairs: residual pieces of all m-tiles requested behind the window's LDS write (A/B builds: 0 = in the epilogue)
+#endif
 
 #ifndef IRIS_B16_PAIR_SUM_DEFAULT
 #define IRIS_B16_PAIR_SUM_DEFAULT 1      // the stage's last pair on the summing kernel (A/B builds: 0)
@@ -214,6 +218,33 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
                 for (int r = 0; r < 16; ++r) acc[m][nt][r] = bias4[nt][r >> 2][r & 3];
     };
 
+    // epilogue geometry (IRIS_B16_RES_EARLY: the residual pieces of ALL m-tiles are requested right behind the window, while its lines
+    // are still in the L2 -- the epilogue's re-read of x otherwise comes from HBM again: 2.0x the compulsory reads, profiles/r03zz_bf16_c3_hbm_traffic.json)
+    constexpr int RS = NT * 32 * 4 + 16;               // scratch row stride (bytes) = 16 * odd
+    constexpr int PPRO = NT * 4;                       // 16-byte bf16 pieces per row of this wave's channel span
+    constexpr int NP = 2 * NT;                         // pieces per lane and m-tile
+    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + item, tensor_bytes);
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.x + item, (a.ablate & 8) ? 0u : tensor_bytes);
+    unsigned pvoff[MT][NP];
+    int pscr[NP];
+    auto geometry = [&](int lane_) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = j * 64 + lane_;
+            const int row_l = q / PPRO, pc = q - row_l * PPRO;
+            pscr[j] = row_l * RS + pc * 32;
+            const int co = ct0 * 32 + 8 * pc;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int im = (wt * MT + m) * 32 + row_l;
+                const int o = o0 + im;
+                pvoff[m][j] = (im < T_OUT && o < L) ? (unsigned)(o * C + co) * 2u : kOob;
+            }
+        }
+    };
+    constexpr int RBUF = IRIS_B16_RES_EARLY ? MT : 2;
+    u32x4 resv[RBUF][NP];
+    if constexpr (IRIS_B16_RES_EARLY) geometry(lane);   // (for the early requests; computed again in front of the epilogue, see there)
     // ---- 1. requests, oldest first: bias1, conv1's first weight fragments (L2), then the whole x window (HBM) ----------
     f32x4 bias4[NT][4];
     load_bias(bias4, p.b1);
@@ -242,6 +273,14 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
             }
             if (idx < total) *reinterpret_cast<u32x4*>(lds + r * SB + pc * 16) = o;
         }
+    }
+    if constexpr (IRIS_B16_RES_EARLY) {
+        // the residual pieces of every m-tile, behind the window's LDS write: their lines are still in the L2 (the window load brought
+        // them in a few microseconds ago), and the barrier below covers their latency
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) resv[m][j] = buf_load4(rr, pvoff[m][j], 0);
     }
     PAIR_STAMP(1);
     __syncthreads();
@@ -272,30 +311,17 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
                 *reinterpret_cast<u32x2*>(lds + row_l * SB + ((ct0 + nt) * 32 + 8 * g + 4 * hi) * 2) = o;
             }
     }
-    // epilogue geometry and the residual of the first m-tile: requested now, back long before the epilogue
-    constexpr int RS = NT * 32 * 4 + 16;               // scratch row stride (bytes) = 16 * odd
-    constexpr int PPRO = NT * 4;                       // 16-byte bf16 pieces per row of this wave's channel span
-    constexpr int NP = 2 * NT;                         // pieces per lane and m-tile
-    const __amdgpu_buffer_rsrc_t yr = make_rsrc(p.y + item, tensor_bytes);
-    const __amdgpu_buffer_rsrc_t rr = make_rsrc(p.x + item, (a.ablate & 8) ? 0u : tensor_bytes);
-    unsigned pvoff[MT][NP];
-    int pscr[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int q = j * 64 + lane;
-        const int row_l = q / PPRO, pc = q - row_l * PPRO;
-        pscr[j] = row_l * RS + pc * 32;
-        const int co = ct0 * 32 + 8 * pc;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int im = (wt * MT + m) * 32 + row_l;
-            const int o = o0 + im;
-            pvoff[m][j] = (im < T_OUT && o < L) ? (unsigned)(o * C + co) * 2u : kOob;
-        }
+    {
+        // (IRIS_B16_RES_EARLY: the offsets are computed a second time, from a lane index the compiler cannot see through, so that
+        //  they do not occupy eight registers across both MFMA loops)
+        int lane2 = lane;
+        if constexpr (IRIS_B16_RES_EARLY) asm volatile("" : "+v"(lane2));
+        geometry(lane2);
     }
-    u32x4 resv[2][NP];
+    if constexpr (!IRIS_B16_RES_EARLY) {             // the residual of the first m-tile: requested now, back long before the epilogue
 #pragma unroll
-    for (int j = 0; j < NP; ++j) resv[0][j] = buf_load4(rr, pvoff[0][j], 0);
+        for (int j = 0; j < NP; ++j) resv[0][j] = buf_load4(rr, pvoff[0][j], 0);
+    }
     __syncthreads();
     PAIR_STAMP(4);
     // ---- 4. conv2 (dilation 1; rows M .. M+k-2 of the window hold stale bytes: they only reach outputs >= T_OUT) ----
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
     char* scr = lds + wave * (32 * RS);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        if (m + 1 < MT) {
+        if (!IRIS_B16_RES_EARLY && m + 1 < MT) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) resv[(m + 1) & 1][j] = buf_load4(rr, pvoff[m + 1][j], 0);
         }
@@ -331,7 +357,7 @@ __global__ void __launch_bounds__(256, MINB) mrf_pair_bf16_kernel(const PairLaun
         for (int j = 0; j < NP; ++j) {
             const f32x4 lo4 = *reinterpret_cast<const f32x4*>(scr + pscr[j]);
             const f32x4 hi4 = *reinterpret_cast<const f32x4*>(scr + pscr[j] + 16);
-            const u32x4 rv = resv[m & 1][j];
+            const u32x4 rv = resv[IRIS_B16_RES_EARLY ? m : (m & 1)][j];
             outp[j][0] = pack_bf2(lo4[0] + bf_lo(rv[0]), lo4[1] + bf_hi(rv[0]));
             outp[j][1] = pack_bf2(lo4[2] + bf_lo(rv[1]), lo4[3] + bf_hi(rv[1]));
             outp[j][2] = pack_bf2(hi4[0] + bf_lo(rv[2]), hi4[1] + bf_hi(rv[2]));
