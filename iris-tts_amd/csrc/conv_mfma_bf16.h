@@ -41,6 +41,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef IRIS_B16_XCD_FOLD
+#define IRIS_B16_XCD_FOLD 1     // 0: XCD grouping per batch item only (the round-3 form; A/B builds)
+#endif
+
+#ifndef IRIS_B16_UPS32_MT
+#define IRIS_B16_UPS32_MT 3     // m-tiles per wave of the ConvTranspose phases at C_out <= 32 (A/B builds)
+#endif
+
 enum InAct : int { IN_ACT_NONE = 0, IN_ACT_LRELU = 1, IN_ACT_MRF_LRELU = 2 };
 
 constexpr int kMaxGroup = 4;
@@ -77,7 +85,9 @@ struct Launch {
     int n_ct;             // 32-wide C_out tiles in the packed weights
     int n_items;          // window items: time tiles (x nz when z is a problem index)
     int n_share;          // consecutive sub-blocks that stage the same window: C_out blocks (x phases for a ConvTranspose)
-    int xcd_group;        // the sub-blocks of a window item share an XCD (see the kernel)
+    int xcd_group;        // the sub-blocks of a window item share an XCD (see the kernel); the batch index is then part
+                          // of the window item (item = b * n_items + tile), so that short items of a large batch qualify too
+    int fold_b;           // grouped launches: the batch index is part of blockIdx.x (item = b * n_items + tile)
     int z_in_y;           // the problem index is blockIdx.y / B (heaviest problem dispatched first, over ALL tiles and batch items)
     int ablate;           // diagnostics only (env IRIS_B16_ABLATE): 1 no staging loads, 2 no MFMA loop, 4 no stores,
                           // 8 no residual loads, 16 every weight fragment from one (L1-resident) address.  Results are wrong.
@@ -271,12 +281,18 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     // With xcd_group they are given the same XCD (blockIdx.x % 8) and neighbouring slots, so the window is fetched
     // from HBM once and re-read from that XCD's L2 (measured without it: the phase blocks of an upsample launch
     // fetched the input u times, 1.5 GB instead of 0.2 GB per launch at configs[2]).
+    // (Round 4: the batch index is folded into the item index of a grouped launch.  Before, grouping needed >= 64 tiles
+    //  PER BATCH ITEM, which configs[2] -- 32 items of 32 tiles -- does not have: its first two upsamplers fetched their
+    //  input 8x and the C = 256 MRF steps 2x, profiles/r04zz_bf16_c3_hbm_traffic.json.)
     int w_item, sub;
+    int b = blockIdx.y;
     if (a.xcd_group) {
         const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
         sub = s % a.n_share;
-        w_item = (s / a.n_share) * 8 + xcd;
-        if (w_item >= a.n_items) return;
+        const int w_lin = (s / a.n_share) * 8 + xcd;
+        if (w_lin >= a.n_items * (a.fold_b ? a.B : 1)) return;
+        if (a.fold_b) { b = w_lin / a.n_items; w_item = w_lin - b * a.n_items; }
+        else w_item = w_lin;
     } else {
         sub = blockIdx.x % a.n_share;
         w_item = blockIdx.x / a.n_share;
@@ -285,8 +301,8 @@ __global__ void __launch_bounds__(256, MINB) conv_mfma_bf16_kernel(const Launch 
     // whole grid -- problem index in blockIdx.y, which is dispatched slowest -- so that the launch ends on short jobs.
     // (Measured: -2 % on the C = 256 MRF launches of configs[2].)
     int tile_co, tile_t, zr;
-    int b = blockIdx.y;
     if (a.z_is_phase)   { zr = sub / a.n_co_blk; tile_co = sub - zr * a.n_co_blk; tile_t = w_item; }
+    else if (a.z_in_y && a.fold_b) { tile_co = sub; tile_t = w_item; zr = blockIdx.y; }
     else if (a.z_in_y)  { tile_co = sub; tile_t = w_item; zr = blockIdx.y / a.B; b = blockIdx.y - zr * a.B; }
     else                { tile_co = sub; zr = w_item % a.nz; tile_t = w_item / a.nz; }
     const int z = a.z_is_phase ? zr : a.nz - 1 - zr;
@@ -537,14 +553,14 @@ inline void pack_convt_bf16(const float* w, int C_in, int C_out, int k, int u, u
 // ---- launch ----------------------------------------------------------------------------------------
 struct Tile { int WT, WC, MT, NT, CIC, MINB, T_BLK, CO_BLK; };
 
-inline Tile pick_tile(int C_in, int C_out) {
+inline Tile pick_tile(int C_in, int C_out, bool phases = false) {
     const int v32 = IRIS_DIAG_ENV("IRIS_B16_TILE32", 0), v64 = IRIS_DIAG_ENV("IRIS_B16_TILE64", 0), v128 = IRIS_DIAG_ENV("IRIS_B16_TILE128", 0);
     Tile t;
     if (C_out <= 32) {
         t.WT = 4; t.WC = 1; t.NT = 1;
         // default: 384 rows at <= 128 VGPRs -> four blocks per CU (HBM-bound layers want requests in flight);
         // diagnostics: v32 = 8 -> 512 rows / 3 blocks, else bit0 -> MT=2, bits1.. -> min blocks 2/3/4
-        if (v32 == 0)      { t.MT = 3; t.MINB = 4; }
+        if (v32 == 0)      { t.MT = phases ? IRIS_B16_UPS32_MT : 3; t.MINB = 4; }
         else if (v32 == 8) { t.MT = 4; t.MINB = 2; }
         else               { t.MT = (v32 & 1) ? 2 : 4; t.MINB = 2 + (v32 >> 1); }
     } else if (C_out <= 64) {
@@ -567,7 +583,7 @@ inline Tile pick_tile(int C_in, int C_out) {
 
 // Fills the derived fields of `a` and launches.  `nz` = problems or phases.
 inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
-    const Tile t = pick_tile(a.C_in, a.C_out);
+    const Tile t = pick_tile(a.C_in, a.C_out, a.z_is_phase != 0);
     a.n_co_blk = (a.C_out + t.CO_BLK - 1) / t.CO_BLK;
     a.Qp = packed_qsteps(a.C_in);
     a.n_ct = packed_cotiles(a.C_out);
@@ -595,9 +611,17 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     a.n_items = (a.z_is_phase || a.z_in_y) ? n_t : n_t * nz;
     a.n_share = a.z_is_phase ? a.n_co_blk * nz : a.n_co_blk;
     const int xcd_env = IRIS_DIAG_ENV("IRIS_B16_XCDGROUP", 1);
-    a.xcd_group = xcd_env && a.n_share > 1 && a.n_items >= 64;      // (a few items would leave XCDs without work)
-    const int gx = a.xcd_group ? ((a.n_items + 7) / 8) * 8 * a.n_share : a.n_items * a.n_share;
-    dim3 grid((unsigned)gx, (unsigned)(a.z_in_y ? a.B * nz : a.B), 1u), block(256);
+    // grouped launches carry the batch index in blockIdx.x (item = b * n_items + tile; blockIdx.y is the z index alone
+    // when z_in_y, else 1)
+    a.fold_b = IRIS_B16_XCD_FOLD;
+    const long long items_all = (long long)a.n_items * (a.fold_b ? a.B : 1);
+    const long long gx_grouped = ((items_all + 7) / 8) * 8 * a.n_share;
+    a.xcd_group = xcd_env && a.n_share > 1 && items_all >= 64 && gx_grouped < 0x7fffffffLL;   // (a few items would leave XCDs without work)
+    const long long gx = a.xcd_group ? gx_grouped : (long long)a.n_items * a.n_share;
+    if (gx > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.fold_b = a.fold_b && a.xcd_group;
+    const unsigned gy = a.fold_b ? (unsigned)(a.z_in_y ? nz : 1) : (unsigned)(a.z_in_y ? a.B * nz : a.B);
+    dim3 grid((unsigned)gx, gy, 1u), block(256);
 #define IRIS_B16_LAUNCH(...)                                                                      \
     do {                                                                                          \
         auto kfn = __VA_ARGS__;                                                                   \
@@ -608,7 +632,7 @@ inline hipError_t launch_conv_bf16(Launch& a, int nz, hipStream_t stream) {
     if (t.WT == WT_ && t.WC == WC_ && t.MT == MT_ && t.NT == NT_ && t.CIC == CIC_ && t.MINB == MINB_) \
         IRIS_B16_LAUNCH(conv_mfma_bf16_kernel<WT_, WC_, MT_, NT_, CIC_, MINB_>)
     IRIS_B16_CASE(4, 1, 4, 1, 32, 2); IRIS_B16_CASE(4, 1, 4, 1, 32, 3); IRIS_B16_CASE(4, 1, 4, 1, 32, 4);
-    IRIS_B16_CASE(4, 1, 3, 1, 32, 4); IRIS_B16_CASE(4, 1, 3, 1, 64, 4);
+    IRIS_B16_CASE(4, 1, 3, 1, 32, 4); IRIS_B16_CASE(4, 1, 3, 1, 64, 4); IRIS_B16_CASE(4, 1, 1, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 1, 32, 2); IRIS_B16_CASE(4, 1, 2, 1, 32, 3); IRIS_B16_CASE(4, 1, 2, 1, 32, 4);
     IRIS_B16_CASE(4, 1, 4, 1, 64, 2); IRIS_B16_CASE(4, 1, 4, 1, 64, 3); IRIS_B16_CASE(4, 1, 4, 1, 64, 4);
     IRIS_B16_CASE(4, 1, 2, 1, 64, 2); IRIS_B16_CASE(4, 1, 2, 1, 64, 3); IRIS_B16_CASE(4, 1, 2, 1, 64, 4);

@@ -7,6 +7,7 @@
 #include "generator_internal.h"
 #include "host_parallel.h"
 #include "conv_mfma_bf16.h"
+#include "convt_mfma_bf16.h"
 #include "mrf_pair_bf16.h"
 #include "conv_mfma_f32s.h"
 #include "conv_post.h"
@@ -257,7 +258,7 @@ int bf16_forward(iris_hifigan_handle* h, const void* mel_dev, int B, int T, void
             a.slope = slope;
             TRY(prof.begin(1, (int)i, 0, 2.0 * fB * L * l.C_in * l.C_out * l.k,
                            2.0 * (fB * L * l.C_in * n_in + fB * L_out * l.C_out + (double)l.ref_w_floats) + 4.0 * l.C_out));
-            HIP_TRY(launch_conv_bf16(a, l.u, stream));
+            HIP_TRY(launch_convt_bf16(a, l.k, l.u, stream));      // one GEMM launch (convt_mfma_bf16.h) where it applies
             TRY(prof.end());
         }
         // ---- MRF: num_kernels ResBlocks advance together (hifigan_pretrained.py:64-71,131-136) ----
@@ -600,7 +601,7 @@ int32_t iris_hifigan_op_conv_transpose1d_bf16(const void* x_dev, const float* w_
     a.out_stride = u; a.out_off = -(k - u) / 2; a.z_is_phase = 1;
     a.phase_wp_bytes = (unsigned)(phase_halfs * 2);
     a.in_act = in_act ? IN_ACT_LRELU : IN_ACT_NONE; a.slope = slope;
-    HIP_TRY(launch_conv_bf16(a, u, stream));
+    HIP_TRY(launch_convt_bf16(a, k, u, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return IRIS_HIFIGAN_OK;
     IRIS_ABI_END

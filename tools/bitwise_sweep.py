@@ -4,7 +4,8 @@ import os, subprocess, sys, json
 import numpy as np
 shapes = [(1, t) for t in (1, 2, 3, 5, 7, 13, 31, 40, 50, 63, 64, 65, 77, 99, 100, 117, 118, 119, 127, 128, 129, 150, 199, 230, 257, 282, 301, 333, 390, 391, 450)] + \
          [(2, 50), (2, 117), (3, 33), (3, 100), (4, 64), (5, 21), (7, 13), (8, 40), (12, 40), (16, 9), (2, 282), (3, 200), (1, 700), (1, 1000), (4, 500)] + \
-         [(1, t) for t in (350, 400, 500, 550, 600, 650, 750, 800, 850, 900, 950, 1100, 1400, 1600)] + [(2, 700), (3, 500), (4, 400)]   # snake-ordered job plans
+         [(1, t) for t in (350, 400, 500, 550, 600, 650, 750, 800, 850, 900, 950, 1100, 1400, 1600)] + [(2, 700), (3, 500), (4, 400)] + \
+         [(32, 500), (8, 300), (9, 130), (24, 57)]   # snake-ordered job plans; batches whose tiles qualify for XCD grouping only together
 if len(sys.argv) > 3:          # optional third argument: that many extra random shapes (seeded): 1 <= B <= 5, 1 <= T <= 1600
     rng = np.random.default_rng(20260)
     shapes = shapes + [(int(rng.integers(1, 6)), int(rng.integers(1, 1601))) for _ in range(int(sys.argv[3]))]
