@@ -30,6 +30,10 @@ namespace b16 {
 #define IRIS_CONVT_GEMM_B16_DEFAULT 1     // (A/B builds: 0 = the polyphase launches of conv_mfma_bf16.h)
 #endif
 
+#ifndef IRIS_CONVT_B16_WIDE_A
+#define IRIS_CONVT_B16_WIDE_A 1           // (A/B builds: 0 = never the 64 x 256 block shape)
+#endif
+
 struct ConvtLaunch {
     const uint16_t* x[3];    // NIN = 1: x[0]; NIN = 3: the previous stage's three branch outputs (MRF mean formed while staging)
     const void* wp;          // u phase blobs of pack_convt_bf16
@@ -43,7 +47,8 @@ struct ConvtLaunch {
     int n_row_tiles;         // row tiles per batch item
     int n_items;             // row tiles over the whole batch
     int n_col_blk;           // column blocks of a row tile
-    int jobs_per_xcd;        // ceil(n_items / 8) * n_col_blk
+    int xcd_order;           // jobs dealt to the XCDs by row item (else one list over the whole grid)
+    int jobs_per_xcd;        // xcd_order: ceil(n_items / 8) * n_col_blk; else n_items * n_col_blk
     int in_act;              // IN_ACT_NONE / IN_ACT_LRELU (NIN = 1), IN_ACT_MRF_LRELU (NIN = 3)
     float slope, inv_n;
 };
@@ -122,12 +127,17 @@ __global__ void __launch_bounds__(256, MINB) convt_mfma_bf16_kernel(const ConvtL
     // ---- jobs: XCD x (= blockIdx.x % 8) owns the row items x, x + 8, ...; its blocks walk (item, column block) with the
     //      column block fastest.  job -> tile ----
     struct Tile { size_t x_off, y_off; int i0, gct0; unsigned wvoff[NT]; };
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    auto job_valid = [&](int job) { return job < a.jobs_per_xcd && (job / a.n_col_blk) * 8 + xcd < a.n_items; };
+    // (xcd_order = 0: one job list for the whole grid -- a single column block, or so few row items that dealing them to
+    //  XCDs would leave some of the eight with a job more than the others)
+    const int xmul = a.xcd_order ? 8 : 1;
+    const int xcd = a.xcd_order ? (int)(blockIdx.x & 7) : 0;
+    const int slot = a.xcd_order ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int slots = a.xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    auto job_valid = [&](int job) { return job < a.jobs_per_xcd && (job / a.n_col_blk) * xmul + xcd < a.n_items; };
     auto make_tile = [&](int job) {
         Tile t;
         const int il = job / a.n_col_blk, cb = job - il * a.n_col_blk;
-        const int item = il * 8 + xcd;
+        const int item = il * xmul + xcd;
         const int b = item / a.n_row_tiles, rt = item - b * a.n_row_tiles;
         t.x_off = (size_t)b * a.L_in * C;
         t.y_off = (size_t)b * a.L_out * a.C_out;
@@ -331,7 +341,7 @@ inline hipError_t launch_convt_gemm_b16(ConvtLaunch& a, int k, hipStream_t strea
     ConvtTile t;
     auto blocks_of = [&](int rows, int cols32) { return (long long)((a.n_idx + rows - 1) / rows) * (n_cols32 / cols32) * a.B; };
     if (CIC == 128) {
-        if ((n_cols32 & 7) == 0 && blocks_of(64, 8) >= 2LL * n_cu) t = ConvtTile{2, 2, 1, 4, 128, 2};
+        if (IRIS_CONVT_B16_WIDE_A && (n_cols32 & 7) == 0 && blocks_of(64, 8) >= 2LL * n_cu) t = ConvtTile{2, 2, 1, 4, 128, 2};
         else if ((n_cols32 & 3) == 0) t = ConvtTile{2, 1, 1, 4, 128, 3};
         else return hipErrorInvalidValue;
     } else {
@@ -344,19 +354,26 @@ inline hipError_t launch_convt_gemm_b16(ConvtLaunch& a, int k, hipStream_t strea
     const long long n_items = (long long)a.n_row_tiles * a.B;
     if (n_items * a.n_col_blk > 0x3fffffffLL) return hipErrorInvalidValue;
     a.n_items = (int)n_items;
-    a.jobs_per_xcd = (int)((n_items + 7) / 8) * a.n_col_blk;
+    // XCD order where column blocks share a window and the eight XCDs get the same number of row items (+-12.5 %)
+    const long long items8 = ((n_items + 7) / 8) * 8;
+    a.xcd_order = a.n_col_blk > 1 && (items8 - n_items) * 8 <= n_items;
+    const int xm = a.xcd_order ? 8 : 1;
+    a.jobs_per_xcd = a.xcd_order ? (int)(items8 / 8) * a.n_col_blk : (int)(n_items * a.n_col_blk);
     a.inv_n = a.in_act == IN_ACT_MRF_LRELU ? 1.0f / 3.0f : 1.0f;
     const bool three = a.in_act == IN_ACT_MRF_LRELU;
-    // persistent grid: per XCD at most per_cu * (CUs / 8) blocks, evened out so that every block walks the same number of jobs (+-1)
+    // persistent grid: at most per_cu blocks per CU (per XCD: per_cu * CUs / 8), evened out so that every block walks the
+    // same number of jobs (+-1)
     const size_t lds_bytes = (size_t)(rows + 1) * (CIC * 2 + 16) + (size_t)4 * 32 * (t.NT * 128 + 16) + (size_t)a.C_out * 4;
     long long per_cu = (!three && t.NT == 1) ? 4 : t.MINB;      // (the one-input narrow forms compile to <= 128 VGPRs)
     { const long long by_lds = (long long)(160 * 1024) / (long long)lds_bytes; if (by_lds < per_cu) per_cu = by_lds; }
     if (per_cu < 1) return hipErrorInvalidValue;
-    long long g = a.jobs_per_xcd < per_cu * (n_cu / 8) ? a.jobs_per_xcd : per_cu * (n_cu / 8);
+    const long long cap = per_cu * (n_cu / xm);
+    long long g = a.jobs_per_xcd < cap ? a.jobs_per_xcd : cap;
     if (g < 1) g = 1;
     const long long rounds = (a.jobs_per_xcd + g - 1) / g;
     g = (a.jobs_per_xcd + rounds - 1) / rounds;
-    dim3 grid((unsigned)(g * 8), 1u, 1u), block(256);
+    g *= xm;
+    dim3 grid((unsigned)g, 1u, 1u), block(256);
 #define IRIS_CONVT_B16_CASE(MT_, NT_, WR_, WC_, CIC_, MINB_)                                                                   \
     if (t.MT == MT_ && t.NT == NT_ && t.WR == WR_ && t.CIC == CIC_) {                                                         \
         if (three) return ::iris::launch_kernel_named("convt_mfma_bf16_kernel<" #MT_ ", " #NT_ ", " #WR_ ", " #WC_ ", " #CIC_ ", 3>", \

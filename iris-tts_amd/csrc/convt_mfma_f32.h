@@ -39,6 +39,10 @@ struct ConvtLaunch {
     int Gp, n_ct;            // packed_groups(C_in), packed_cotiles(C_out): the layout of one phase blob
     unsigned phase_bytes;    // bytes between consecutive phase blobs
     int n_row_tiles, n_col_blk, n_tiles;   // per batch item / per batch item / over the whole batch
+    int n_items;             // row tiles over the whole batch
+    int xcd_order;           // jobs dealt to the XCDs by row item (the column blocks of a row tile share a window: one XCD's L2
+                             // then fetches it once); else one job list over the whole grid
+    int jobs_per_xcd;        // xcd_order: ceil(n_items / 8) * n_col_blk; else n_tiles
     float slope;
 };
 
@@ -110,11 +114,15 @@ __global__ void __launch_bounds__(256, 2) convt_mfma_f32_kernel(const ConvtLaunc
 
     // ---- a tile = (batch item, row tile, column block); column blocks fastest ----
     struct Tile { size_t x_off, y_off; int i0; unsigned wvoff[NT]; int ch[NT]; int ph[NT]; };
-    auto make_tile = [&](int tile) {
+    const int xmul = a.xcd_order ? 8 : 1;
+    const int xcd = a.xcd_order ? (int)(blockIdx.x & 7) : 0;
+    const int slots = a.xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    auto job_valid = [&](int job) { return job < a.jobs_per_xcd && (job / a.n_col_blk) * xmul + xcd < a.n_items; };
+    auto make_tile = [&](int job) {
         Tile t;
-        const int per_item = a.n_row_tiles * a.n_col_blk;
-        const int b = tile / per_item, rem = tile - b * per_item;
-        const int rt = rem / a.n_col_blk, cb = rem - rt * a.n_col_blk;
+        const int il = job / a.n_col_blk, cb = job - il * a.n_col_blk;
+        const int item = il * xmul + xcd;
+        const int b = item / a.n_row_tiles, rt = item - b * a.n_row_tiles;
         t.x_off = (size_t)b * a.L_in * C;
         t.y_off = (size_t)b * a.L_out * a.C_out;
         t.i0 = rt * R_BLK;
@@ -133,8 +141,8 @@ __global__ void __launch_bounds__(256, 2) convt_mfma_f32_kernel(const ConvtLaunc
     f32x16 acc[MT][NT];
     f32x4 bw[DB + 1][NT];
 
-    int tile = blockIdx.x;
-    if (tile >= a.n_tiles) return;
+    int tile = a.xcd_order ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;       // (a job index of this block's list)
+    if (!job_valid(tile)) return;
     Tile t = make_tile(tile);
     {   // prologue: the first window and the first weight fragments
         const unsigned vb0 = stage_vbase(t.i0 - (TAPS - 1), 0);
@@ -148,8 +156,8 @@ __global__ void __launch_bounds__(256, 2) convt_mfma_f32_kernel(const ConvtLaunc
         __syncthreads();
     }
     for (;;) {
-        const int tile_next = tile + (int)gridDim.x;
-        const bool more = tile_next < a.n_tiles;
+        const int tile_next = tile + slots;
+        const bool more = job_valid(tile_next);
         const Tile tn = make_tile(more ? tile_next : tile);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -295,6 +303,9 @@ inline bool convt_gemm_applicable(int C_in, int C_out, int k, int u, int L_in, i
     return true;
 }
 
+#ifndef IRIS_CONVT_XCD_ORDER
+#define IRIS_CONVT_XCD_ORDER 1           // (A/B builds: 0 = one job list over the whole grid, as before)
+#endif
 #ifndef IRIS_CONVT_PER_CU
 #define IRIS_CONVT_PER_CU 4              // resident blocks per CU of the light shapes (70-118 VGPRs, 9-35 KB of LDS); 64 x 256 blocks: two
 #endif
@@ -322,14 +333,22 @@ inline hipError_t launch_convt_gemm(ConvtLaunch& a, int k, hipStream_t stream) {
     const long long n_tiles = (long long)a.n_row_tiles * a.n_col_blk * a.B;
     if (n_tiles > 0x3fffffffLL) return hipErrorInvalidValue;
     a.n_tiles = (int)n_tiles;
+    // XCD order where column blocks share a window and the eight XCDs get the same number of row items (+-12.5 %)
+    const long long n_items = (long long)a.n_row_tiles * a.B, items8 = ((n_items + 7) / 8) * 8;
+    a.n_items = (int)n_items;
+    a.xcd_order = IRIS_CONVT_XCD_ORDER && a.n_col_blk > 1 && (items8 - n_items) * 8 <= n_items;
+    const int xm = a.xcd_order ? 8 : 1;
+    a.jobs_per_xcd = a.xcd_order ? (int)(items8 / 8) * a.n_col_blk : (int)n_tiles;
     // persistent grid: at most per_cu blocks per CU, evened out so that every block walks the same number of tiles (+-1)
     // (what the registers allow: 64 x 256 blocks 161-200 VGPRs; one input 110-127; three-input staging 135-152, 200 at 128 x 64)
     const bool three_in = a.x1 != nullptr;
     const long long per_cu = t.NT == 2 ? 2 : (three_in ? (t.WR == 2 ? 2 : 3) : IRIS_CONVT_PER_CU);
-    long long g = n_tiles < per_cu * n_cu ? n_tiles : per_cu * n_cu;
+    const long long cap = per_cu * (n_cu / xm);
+    long long g = a.jobs_per_xcd < cap ? a.jobs_per_xcd : cap;
     if (g < 1) g = 1;
-    const long long rounds = (n_tiles + g - 1) / g;
-    g = (n_tiles + rounds - 1) / rounds;
+    const long long rounds = (a.jobs_per_xcd + g - 1) / g;
+    g = (a.jobs_per_xcd + rounds - 1) / rounds;
+    g *= xm;
     const size_t lds_bytes = ((size_t)(rows + taps - 1) * 68 + (size_t)a.C_out) * sizeof(float);
     dim3 grid((unsigned)g, 1u, 1u), block(256);
     if (taps != 2) return hipErrorInvalidValue;

@@ -101,7 +101,10 @@ def test_bf16_conv1d_matches_oracle(B, L, Ci, Co, k, d, act, use_res):
 
 @pytest.mark.parametrize("B,L,Ci,Co,k,u", [(1, 40, 512, 256, 16, 8), (2, 130, 256, 128, 16, 8), (1, 300, 128, 64, 4, 2),
                                             (2, 517, 64, 32, 4, 2), (1, 1, 64, 32, 4, 2), (1, 9, 32, 16, 7, 3),
-                                            (1, 25000, 64, 32, 4, 2)])   # 66 window items x 2 phases: XCD-grouped
+                                            (1, 25000, 64, 32, 4, 2),    # 66 window items x 2 phases: XCD-grouped
+                                            # round 4, the GEMM form (convt_mfma_bf16.h): 64 x 256 blocks (>= 2 per CU), a second
+                                            # row tile of two rows, nine batch items over the eight XCDs
+                                            (4, 2100, 256, 128, 16, 8), (3, 65, 512, 256, 16, 8), (9, 63, 128, 64, 4, 2)])
 def test_bf16_conv_transpose1d_matches_oracle(B, L, Ci, Co, k, u):
     from iris import _native
     lib = _native.load()
