@@ -570,7 +570,7 @@ inline Tile pick_tile(int C_in, int C_out, bool phases = false) {
         else               { t.WT = 4; t.WC = 1; t.NT = 2; t.MT = (v64 & 1) ? 1 : 2; t.MINB = v64 == 8 ? 2 : 2 + (v64 >> 1); }
     } else {
         t.WT = 2; t.WC = 2; t.NT = 2;
-        t.MT = 2;
+        t.MT = 2;             // (96 rows per wave, MT = 3: -1.5 % on the C = 256 steps of configs[2], -15 % at 1 x 1000: profiles/r04_notes.md section 15)
         t.MINB = 2;
     }
     t.CIC = (C_in <= 32 && t.NT == 1 && t.WC == 1) ? 32 : 64;
