@@ -34,6 +34,9 @@
 #define IRIS_B16_RES_EARLY 1     // fused pairs: residual pieces of all m-tiles requested behind the window's LDS write (A/B builds: 0 = in the epilogue)
 #endif
 
+#ifndef IRIS_B16_RING_TAIL_GUARD
+#define IRIS_B16_RING_TAIL_GUARD 1       // (A/B builds: 0 = the ring's last trip runs all its groups, zero fragments included)
+#endif
 #ifndef IRIS_B16_PAIR_SUM_DEFAULT
 #define IRIS_B16_PAIR_SUM_DEFAULT 1      // the stage's last pair on the summing kernel (A/B builds: 0)
 #endif
@@ -121,22 +124,34 @@ __device__ __forceinline__ void ring_mma_loop(f32x16 (&acc)[MT][NT], u32x4 (&wv)
     };
     u32x4 av[2][MT];
     load_a(av[0], 0);
-    for (int n0 = 0; n0 < NG; n0 += D) {
+    auto group = [&](int i, int n) {
+        load_a(av[(i + 1) & 1], n + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const int n = n0 + i;
-            load_a(av[(i + 1) & 1], n + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int m = 0; m < MT; ++m)
+                acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, wv[i][nt]), __builtin_bit_cast(bf16x8, av[i & 1][m]), acc[m][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, wv[i][nt]), __builtin_bit_cast(bf16x8, av[i & 1][m]), acc[m][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NT; ++nt)
+            wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(n + D));   // past the last tap: out of range, zeros
+    };
+    // C = 32 (QPC = 2 groups per tap, D = 4, an odd number of taps): the ring's last trip is half empty.  Run whole, its second
+    // half multiplies zero weight fragments (6 / 14 / 22 groups rounded up to 8 / 16 / 24: a seventh of a conv's MFMAs); it is
+    // issued as a tail of QPC groups instead.
+    constexpr bool kTail = IRIS_B16_RING_TAIL_GUARD && (QPC % D) != 0;
+    const int NG_main = kTail ? (NG / D) * D : NG;
+    int n0 = 0;
+    for (; n0 < NG_main; n0 += D) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wv[i][nt] = buf_load4(wr, wvoff + (unsigned)nt * 1024u, w_soff(n + D));   // past the last tap: out of range, zeros
+        for (int i = 0; i < D; ++i) group(i, n0 + i);
+    }
+    if constexpr (kTail) {
+        if (n0 < NG) {
+#pragma unroll
+            for (int i = 0; i < QPC; ++i) group(i, n0 + i);
         }
     }
 }
