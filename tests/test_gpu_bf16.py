@@ -69,6 +69,8 @@ CONV_CASES = [
     (1, 70, 256, 256, 11, 3, 1, True), (1, 264, 256, 256, 3, 1, 1, False),
     (1, 5, 32, 32, 11, 5, 1, True), (1, 1, 64, 64, 3, 1, 1, False), (3, 41, 24, 40, 5, 2, 1, False),
     (1, 9000, 256, 256, 3, 1, 1, True),    # 71 window items x 2 C_out blocks: the XCD-grouped block mapping, ragged
+    (37, 300, 256, 256, 3, 1, 1, True),    # round 4: 3 window items per batch item x 37 items = 111: grouped only with the batch index
+                                           # folded into the item index (Launch::fold_b); 111 is not a multiple of 8
 ]
 
 
